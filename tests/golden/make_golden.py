@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by executing the REFERENCE's own classes.
+
+Runs only in the build container (needs /root/reference).  Nothing here travels as code: the
+outputs are data (inputs, state_dicts, expected outputs) stored as .npz.
+
+The reference imports `ride`, `pytorch_lightning` and `continual`, none of which is installed.
+They are replaced by *name-only* stubs (no arithmetic) so that the clip-path classes --
+GraphConvolution, TemporalConvolution, SpatioTemporalBlock (models/base.py:230-387),
+AdaptiveGraphConvolution (models/a_gcn/a_gcn.py:12-69), Graph (datasets/graph.py) and
+StGcn.__init__/forward (models/st_gcn/st_gcn.py:20-65) -- execute verbatim.
+
+BatchNorm affine/statistics and graph_attn are RANDOMISED: with the default init
+(gcn.bn.weight = 1e-6, models/base.py:256-257) the whole aggregation branch is invisible at 1e-4.
+
+usage: python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from closed_form import closed_form_input, closed_form_state_dict  # noqa: E402
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Cfg:
+        def __init__(self):
+            self.names = []
+
+        def add(self, *a, **k):
+            pass
+
+    def _empty():
+        return type("_Stub", (), {})     # a fresh class each time: they are used as distinct bases
+
+    log = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None)
+    ride = mod(
+        "ride", getLogger=lambda *a, **k: log, Configs=_Cfg, RideModule=nn.Module,
+        TopKAccuracyMetric=lambda *k: type("TopK", (), {}), SgdOneCycleOptimizer=_empty(),
+        Main=lambda *a, **k: None,
+    )
+    ride.core = mod("ride.core", Configs=_Cfg, RideMixin=_empty(), RideClassificationDataset=_empty())
+    ride.logging = mod("ride.logging", getLogger=lambda *a, **k: log)
+    ride.finetune = mod("ride.finetune", Finetunable=_empty())
+    ride.optimizers = mod("ride.optimizers", SgdCyclicLrOptimizer=_empty())
+    mod("pytorch_lightning")
+    mod("pytorch_lightning.utilities")
+    mod("pytorch_lightning.utilities.parsing", AttributeDict=dict)
+    mod("continual", Sequential=type("Sequential", (nn.Sequential,), {}))
+    sys.path.insert(0, REF)   # the reference's `datasets` must shadow the HF package
+    # datasets/__init__ pulls the Lightning data module; provide the two leaf modules only
+    import importlib.util
+
+    pkg = types.ModuleType("datasets")
+    pkg.__path__ = [os.path.join(REF, "datasets")]
+    sys.modules["datasets"] = pkg
+    for leaf in ("graph", "ntu_rgbd", "kinetics"):
+        spec = importlib.util.spec_from_file_location(f"datasets.{leaf}", os.path.join(REF, "datasets", f"{leaf}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"datasets.{leaf}"] = m
+        spec.loader.exec_module(m)
+        setattr(pkg, leaf, m)
+    dsmod = mod("datasets.datasets", GraphDatasets=_empty())
+    pkg.datasets = dsmod
+
+
+def randomise(module: nn.Module, gen: torch.Generator):
+    """BN weight~U(.5,1.5), bias~U(-.5,.5), mean~U(-.5,.5), var~U(.5,1.5); graph_attn~U(.5,1.5);
+    conv biases ~U(-.2,.2) (reference init sets them to 0, which would hide bias-folding bugs)."""
+    def u(shape, lo, hi):
+        return torch.rand(shape, generator=gen) * (hi - lo) + lo
+
+    with torch.no_grad():
+        for name, m in module.named_modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                m.weight.copy_(u(m.weight.shape, 0.5, 1.5))
+                m.bias.copy_(u(m.bias.shape, -0.5, 0.5))
+                m.running_mean.copy_(u(m.running_mean.shape, -0.5, 0.5))
+                m.running_var.copy_(u(m.running_var.shape, 0.5, 1.5))
+            if isinstance(m, (nn.Conv2d, nn.Linear)) and m.bias is not None:
+                m.bias.copy_(u(m.bias.shape, -0.2, 0.2))
+        for name, prm in module.named_parameters():
+            if name.endswith("graph_attn"):
+                prm.copy_(u(prm.shape, 0.5, 1.5))
+
+
+def sd_np(module):
+    return {"sd/" + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def main():
+    _install_stubs()
+    from datasets import kinetics, ntu_rgbd
+    from models.a_gcn.a_gcn import AdaptiveGraphConvolution
+    from models.base import GraphConvolution, SpatioTemporalBlock, TemporalConvolution
+    from models.st_gcn.st_gcn import StGcn
+
+    torch.set_num_threads(4)
+    A_ntu, A_kin = ntu_rgbd.graph.A, kinetics.graph.A
+    save = lambda name, **kw: np.savez_compressed(os.path.join(OUT, name), **kw)  # noqa: E731
+
+    # G0 -- adjacency, exact
+    save("g0_graphs.npz", ntu=A_ntu, kinetics=A_kin)
+
+    # G1 -- GraphConvolution 4->4 (identity gcn_residual) and 3->8 (conv gcn_residual), (2,C,6,25)
+    g = torch.Generator().manual_seed(101)
+    for tag, (ci, co) in {"eq": (4, 4), "neq": (3, 8)}.items():
+        m = GraphConvolution(ci, co, A_ntu).eval()
+        randomise(m, g)
+        x = torch.rand((2, ci, 6, 25), generator=g)
+        with torch.no_grad():
+            y = m(x)
+        save(f"g1_gcn_{tag}.npz", x=x.numpy(), y=y.numpy(), **sd_np(m))
+
+    # G2 -- TemporalConvolution variants, (2,4,20,25) (mirrors tests/test_cost_gcn.py:37-68)
+    g = torch.Generator().manual_seed(102)
+    for tag, (k, s, p) in {"k9s1p4": (9, 1, 4), "k9s2p4": (9, 2, 4), "k1s2p0": (1, 2, 0), "k9s1p0": (9, 1, 0)}.items():
+        m = TemporalConvolution(4, 4, k, s, p).eval()
+        randomise(m, g)
+        x = torch.rand((2, 4, 20, 25), generator=g)
+        with torch.no_grad():
+            y = m(x)
+        save(f"g2_tcn_{tag}.npz", x=x.numpy(), y=y.numpy(), meta=np.array([k, s, p]), **sd_np(m))
+
+    # G3 -- SpatioTemporalBlock variants, T=20, B=2, V=25 (mirrors tests/test_cost_gcn.py:71-271,
+    #       tests/test_st_gcn_mod.py:11-54); each also serves as the step oracle via the index map
+    g = torch.Generator().manual_seed(103)
+    variants = {
+        # tag: (cin, cout, stride, residual, temporal_padding)
+        "nores": (4, 4, 1, False, 4),
+        "ident": (4, 4, 1, True, -1),
+        "convres": (2, 4, 1, True, -1),
+        "strided": (2, 4, 2, True, -1),
+        "nopad": (4, 4, 1, True, 0),
+        "nopad_strided": (2, 4, 2, True, 0),
+    }
+    for tag, (ci, co, s, res, tp) in variants.items():
+        m = SpatioTemporalBlock(ci, co, A_ntu, s, res, temporal_padding=tp).eval()
+        randomise(m, g)
+        x = torch.rand((2, ci, 20, 25), generator=g)
+        with torch.no_grad():
+            y = m(x)
+        save(f"g3_block_{tag}.npz", x=x.numpy(), y=y.numpy(), meta=np.array([ci, co, s, int(res), tp]), **sd_np(m))
+
+    # G4 -- 3-block stack 3->3 (no res) ->3 (identity) ->4 (stride 2), T=40 (tests/test_cost_gcn.py:274-326)
+    g = torch.Generator().manual_seed(104)
+    stack = nn.Sequential(
+        SpatioTemporalBlock(3, 3, A_ntu, residual=False),
+        SpatioTemporalBlock(3, 3, A_ntu),
+        SpatioTemporalBlock(3, 4, A_ntu, stride=2),
+    ).eval()
+    randomise(stack, g)
+    x = torch.rand((2, 3, 40, 25), generator=g)
+    with torch.no_grad():
+        y = stack(x)
+    save("g4_stack.npz", x=x.numpy(), y=y.numpy(), **sd_np(stack))
+
+    # G5 -- BASELINE config 1: SpatioTemporalBlock(3,64,A_ntu,residual=False) on (2,3,300,25)
+    g = torch.Generator().manual_seed(0)
+    m = SpatioTemporalBlock(3, 64, A_ntu, residual=False).eval()
+    randomise(m, g)
+    x = torch.from_numpy(closed_form_input((2, 3, 300, 25), salt=5.0))
+    with torch.no_grad():
+        y = m(x)
+    yf = y.numpy().reshape(-1)
+    save("g5_config1_block.npz", y_sub7=yf[::7].copy(), y_chan_sum=y.sum(dim=(0, 2, 3)).numpy(),
+         y_shape=np.array(y.shape), **sd_np(m))
+
+    # G6 -- full StGcn, NTU N=2 and Kinetics-shape N=1; closed-form input; logits in full,
+    #       layers 1/5/8/10 subsampled
+    for tag, (A, V, classes, n, seed) in {"ntu": (A_ntu, 25, 60, 2, 106), "kin": (A_kin, 18, 400, 1, 107)}.items():
+        g = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        net = StGcn.__new__(StGcn)
+        nn.Module.__init__(net)
+        net.input_shape = (3, 300, V, 2)
+        net.num_classes = classes
+        net.graph = types.SimpleNamespace(A=A)
+        StGcn.__init__(net, {})
+        net.eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        gen = closed_form_state_dict(shapes, salt0=float(seed))
+        full = {k: (torch.from_numpy(gen[k]) if k in gen else v) for k, v in net.state_dict().items()}
+        net.load_state_dict(full)
+        x = torch.from_numpy(closed_form_input((n, 3, 300, V, 2), salt=6.0 + seed))
+        taps = {}
+        hooks = [net.layers[f"layer{i}"].register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, out))
+                 for i in (1, 5, 8, 10)]
+        with torch.no_grad():
+            logits = net(x)
+        for h in hooks:
+            h.remove()
+        extra = {}
+        for i, t in taps.items():
+            extra[f"layer{i}_sub"] = t.numpy().reshape(-1)[::997].copy()
+            extra[f"layer{i}_absmax"] = np.array(float(t.abs().max()))
+        nparams = sum(p.numel() for p in net.parameters())
+        save(f"g6_stgcn_{tag}.npz", logits=logits.numpy(), n=np.array(n), salt=np.array(6.0 + seed),
+             seed=np.array(float(seed)), nparams=np.array(nparams),
+             sd_keys=np.array(list(shapes.keys())), sd_shapes=np.array([str(list(v)) for v in shapes.values()]),
+             **extra)
+
+    # G7 -- AdaptiveGraphConvolution 3->8 and 8->8, V=18, T in {1,6} (T=1 is the CoAGCN step oracle)
+    g = torch.Generator().manual_seed(108)
+    for tag, (ci, co) in {"neq": (3, 8), "eq": (8, 8)}.items():
+        torch.manual_seed(108)
+        m = AdaptiveGraphConvolution(ci, co, A_kin).eval()
+        randomise(m, g)
+        out = {}
+        for t in (1, 6):
+            x = torch.rand((2, ci, t, 18), generator=g)
+            with torch.no_grad():
+                out[f"x_t{t}"] = x.numpy()
+                out[f"y_t{t}"] = m(x).numpy()
+        save(f"g7_agcn_{tag}.npz", **out, **sd_np(m))
+
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
+    print(f"wrote fixtures to {OUT}: {tot / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

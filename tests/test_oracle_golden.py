@@ -1,0 +1,149 @@
+"""Pin the CPU oracle against vectors produced by the reference's own classes (tests/golden/*.npz),
+and check the restated continual protocol with the identities the reference's tests assert."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stgcn_oracle as o
+from tests.helpers import g6_state_dict, load_golden, max_err
+
+TOL = 1e-5  # same op sequence, same library -> differences are last-bit only
+
+
+def test_g0_graphs_exact():
+    arrays, _ = load_golden("g0_graphs")
+    assert np.array_equal(arrays["ntu"], o.ntu_graph())
+    assert np.array_equal(arrays["kinetics"], o.kinetics_graph())
+    # sparsity facts the kernels rely on
+    nnz = [(o.ntu_graph()[i] != 0).sum(0).max() for i in range(3)]
+    assert nnz == [1, 1, 4]
+
+
+@pytest.mark.parametrize("tag", ["eq", "neq"])
+def test_g1_graph_conv(tag):
+    a, sd = load_golden(f"g1_gcn_{tag}")
+    with torch.no_grad():
+        y = o.graph_conv(torch.from_numpy(a["x"]), sd)
+    assert max_err(y, a["y"]) <= TOL
+
+
+@pytest.mark.parametrize("tag", ["k9s1p4", "k9s2p4", "k1s2p0", "k9s1p0"])
+def test_g2_temporal_conv(tag):
+    a, sd = load_golden(f"g2_tcn_{tag}")
+    k, s, p = (int(v) for v in a["meta"])
+    with torch.no_grad():
+        y = o.temporal_conv(torch.from_numpy(a["x"]), sd, "", s, p)
+    assert y.shape == a["y"].shape and max_err(y, a["y"]) <= TOL
+
+
+G3 = ["nores", "ident", "convres", "strided", "nopad", "nopad_strided"]
+
+
+@pytest.mark.parametrize("tag", G3)
+def test_g3_block(tag):
+    a, sd = load_golden(f"g3_block_{tag}")
+    ci, co, s, res, tp = (int(v) for v in a["meta"])
+    with torch.no_grad():
+        y = o.st_block(torch.from_numpy(a["x"]), sd, "", s, bool(res), tp)
+    assert y.shape == a["y"].shape and max_err(y, a["y"]) <= TOL
+
+
+def test_g4_stack():
+    a, sd = load_golden("g4_stack")
+    h = torch.from_numpy(a["x"])
+    with torch.no_grad():
+        for i, (s, res) in enumerate([(1, False), (1, True), (2, True)]):
+            h = o.st_block(h, sd, f"{i}.", s, res)
+    assert max_err(h, a["y"]) <= TOL
+
+
+def test_g5_config1_block():
+    from closed_form import closed_form_input
+
+    a, sd = load_golden("g5_config1_block")
+    x = torch.from_numpy(closed_form_input((2, 3, 300, 25), salt=5.0))
+    with torch.no_grad():
+        y = o.st_block(x, sd, "", 1, False)
+    assert tuple(y.shape) == tuple(a["y_shape"])
+    assert max_err(y.reshape(-1)[::7], a["y_sub7"]) <= 1e-4
+    assert np.allclose(y.sum(dim=(0, 2, 3)).numpy(), a["y_chan_sum"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["ntu", "kin"])
+def test_g6_full_stgcn(tag):
+    a, sd, x = g6_state_dict(tag)
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == int(a["nparams"])
+    taps = {}
+    with torch.no_grad():
+        logits = o.stgcn_forward(x, sd, taps=taps)
+    assert max_err(logits, a["logits"]) <= 1e-4
+    for i in (1, 5, 8, 10):
+        assert max_err(taps[f"layer{i}"].reshape(-1)[::997], a[f"layer{i}_sub"]) <= 1e-4
+
+
+@pytest.mark.parametrize("tag", ["eq", "neq"])
+@pytest.mark.parametrize("t", [1, 6])
+def test_g7_adaptive_graph_conv(tag, t):
+    a, sd = load_golden(f"g7_agcn_{tag}")
+    with torch.no_grad():
+        y = o.adaptive_graph_conv(torch.from_numpy(a[f"x_t{t}"]), sd)
+    assert max_err(y, a[f"y_t{t}"]) <= TOL
+
+
+# ---- continual protocol: the identities asserted by the reference's tests, against pinned clip outputs
+@pytest.mark.parametrize("tag", ["nores", "ident"])
+def test_co_block_step_lags_clip_by_4(tag):
+    """tests/test_cost_gcn.py:71-176: output[t + (k-1-p)] == target[:, :, t] for t in [p, T-(k-1))
+    (and, with a zero-initialised window, for every t >= 0)."""
+    a, sd = load_golden(f"g3_block_{tag}")
+    ci, co, s, res, tp = (int(v) for v in a["meta"])
+    x, target = torch.from_numpy(a["x"]), torch.from_numpy(a["y"])
+    blk = o.CoBlockOracle(sd, "", s, bool(res), padding=4)
+    with torch.no_grad():
+        outs = [blk.forward_step(x[:, :, i]) for i in range(x.shape[2])]
+    assert all(v is None for v in outs[:4])
+    for t in range(0, x.shape[2] - 4):
+        assert max_err(outs[t + 4], target[:, :, t]) <= 1e-5
+
+
+@pytest.mark.parametrize("tag", ["convres", "strided", "ident", "nores"])
+def test_co_block_forward_steps_pad_end(tag):
+    """tests/test_cost_gcn.py:179-271: pad_end=False == target[:, :, :-delay//stride]; pad_end=True == target."""
+    a, sd = load_golden(f"g3_block_{tag}")
+    ci, co, s, res, tp = (int(v) for v in a["meta"])
+    x, target = torch.from_numpy(a["x"]), torch.from_numpy(a["y"])
+    blk = o.CoBlockOracle(sd, "", s, bool(res), padding=4)
+    with torch.no_grad():
+        o1 = blk.forward_steps(x, pad_end=False)
+        blk.clean_state()
+        o2 = blk.forward_steps(x, pad_end=True)
+    cut = blk.delay // s
+    assert o1.shape[2] == target.shape[2] - cut and max_err(o1, target[:, :, : target.shape[2] - cut]) <= 1e-5
+    assert o2.shape == target.shape and max_err(o2, target) <= 1e-5
+
+
+@pytest.mark.parametrize("tag", ["nopad", "nopad_strided"])
+def test_co_block_nopad_equals_cropped(tag):
+    """tests/test_st_gcn_mod.py:11-54: the padding=0 continual block reproduces the un-padded clip block."""
+    a, sd = load_golden(f"g3_block_{tag}")
+    ci, co, s, res, tp = (int(v) for v in a["meta"])
+    x, target = torch.from_numpy(a["x"]), torch.from_numpy(a["y"])
+    blk = o.CoBlockOracle(sd, "", s, bool(res), padding=0)
+    with torch.no_grad():
+        out = blk.forward_steps(x, pad_end=False)
+    assert out.shape == target.shape and max_err(out, target) <= 1e-5
+
+
+def test_co_stack_matches_clip_stack():
+    """tests/test_cost_gcn.py:274-326 (3 stacked blocks, module-wise flush == regular stack)."""
+    a, sd = load_golden("g4_stack")
+    h = torch.from_numpy(a["x"])
+    with torch.no_grad():
+        for i, (s, res) in enumerate([(1, False), (1, True), (2, True)]):
+            h = o.CoBlockOracle(sd, f"{i}.", s, res, padding=4).forward_steps(h, pad_end=True)
+    assert max_err(h, a["y"]) <= 1e-5
+
+
+def test_co_stgcn_geometry_and_pool_defaults():
+    assert o.co_stgcn_geometry() == (153, 76, 4)
+    assert o.co_stgcn_pool_defaults(300) == (75, 19)
