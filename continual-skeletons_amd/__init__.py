@@ -1,0 +1,32 @@
+"""MI355X-native ST-GCN / CoST-GCN forward path.
+
+Drop-in for the block library of LukasHedegaard/continual-skeletons ``models/base.py`` (reference
+names exported unchanged; the north-star aliases ``SpatialGraphConv`` / ``StGcnBlock`` /
+``CoStGcnBlock`` point at them).  All arithmetic runs in hand-written HIP kernels for gfx950 behind
+the C ABI of ``include/cskel.h``; there is no CPU or PyTorch-op fallback -- a missing library or a
+CPU tensor raises.
+
+The directory name carries a hyphen, so it is imported through ``_bootstrap.load()`` (repo root),
+which registers it as the module ``continual_skeletons_amd``.
+"""
+from .graph import Graph, kinetics_graph, ntu_graph  # noqa: F401
+from .blocks import (  # noqa: F401
+    GraphConvolution,
+    SpatioTemporalBlock,
+    TemporalConvolution,
+    init_weights,
+    unity,
+    zero,
+)
+from .models import StGcn  # noqa: F401
+from . import native  # noqa: F401
+
+# names used by BASELINE.json:north_star
+SpatialGraphConv = GraphConvolution
+StGcnBlock = SpatioTemporalBlock
+
+__all__ = [
+    "Graph", "ntu_graph", "kinetics_graph", "GraphConvolution", "TemporalConvolution",
+    "SpatioTemporalBlock", "SpatialGraphConv", "StGcnBlock", "StGcn", "init_weights", "zero", "unity",
+    "native",
+]

@@ -1,0 +1,225 @@
+"""Clip-mode block library: GraphConvolution / TemporalConvolution / SpatioTemporalBlock.
+
+Same constructors, attribute names and ``state_dict`` layout as the reference's
+``models/base.py:230-387`` (an unmodified reference state_dict loads with ``strict=True``), but
+``forward`` launches the fused gfx950 stage kernels through the C ABI (include/cskel.h) instead of
+issuing ~14 ATen ops per block.  Inference only: BatchNorm is folded with its running statistics, so
+a module in training mode raises.  The ``nn.Conv2d`` / ``nn.BatchNorm2d`` children are parameter
+containers (they define the state_dict keys and initialisation); they are never called.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.modules.batchnorm import _BatchNorm
+from torch.nn.modules.conv import _ConvNd
+
+from . import fold, native
+
+
+# ---- models/utils.py:9-32 -----------------------------------------------------------------------
+def init_weights(module_, bs=1):
+    """Initialisation rule of the reference (models/utils.py:9-24)."""
+    if isinstance(module_, _ConvNd):
+        nn.init.constant_(module_.bias, 0)
+        if bs == 1:
+            nn.init.kaiming_normal_(module_.weight, mode="fan_out")
+        else:
+            nn.init.normal_(module_.weight, 0, math.sqrt(2.0 / (module_.weight.numel() * bs)))
+    elif isinstance(module_, _BatchNorm):
+        nn.init.constant_(module_.weight, bs)
+        nn.init.constant_(module_.bias, 0)
+    elif isinstance(module_, nn.Linear):
+        nn.init.normal_(module_.weight, 0, math.sqrt(2.0 / bs))
+
+
+def zero(x):
+    return 0
+
+
+def unity(x):
+    return x
+
+
+# ---- folded-operand cache -------------------------------------------------------------------------
+class _Folded(nn.Module):
+    """Mixin: caches the packed device operands and refolds when any parameter/buffer changed
+    (load_state_dict, .to(), in-place edits) -- SURVEY 8b 'Folding must be redone if weights are reloaded'."""
+
+    def _fingerprint(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _packed_ops(self, device):
+        fp = (self._fingerprint(), str(device))
+        cache = self.__dict__.get("_fold_cache")
+        if cache is None or cache[0] != fp:
+            # "*_host" entries are read by the C ABI on the host (e.g. ell_cnt); everything else lives in HBM
+            ops = {k: (v.to(device) if isinstance(v, torch.Tensor) and not k.endswith("_host") else v)
+                   for k, v in self._fold().items()}
+            self.__dict__["_fold_cache"] = cache = (fp, ops)
+        return cache[1]
+
+    def refold(self):
+        self.__dict__.pop("_fold_cache", None)
+
+    def _require_eval(self):
+        if self.training:
+            raise RuntimeError(
+                f"{type(self).__name__}: the MI355X path is inference-only (BatchNorm folded with running "
+                "statistics); call .eval() first"
+            )
+
+
+def _check_input(x, channels, name):
+    native.require_device_f32(x, name)
+    if x.dim() != 4 or x.shape[1] != channels:
+        raise RuntimeError(f"{name} must be (N, {channels}, T, V), got {tuple(x.shape)}")
+
+
+# ---- models/base.py:230-270 -----------------------------------------------------------------------
+class GraphConvolution(_Folded):
+    """K=3-partition adjacency aggregation + three 1x1 convs + BN + (identity | conv+BN) residual + ReLU."""
+
+    def __init__(self, in_channels, out_channels, A, bn_momentum=0.1, *args, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.graph_attn = nn.Parameter(torch.ones(A.shape, dtype=torch.float32))
+        self.A = nn.Parameter(torch.from_numpy(np.asarray(A).astype(np.float32)), requires_grad=False)
+        self.num_subset = 3
+        self.g_conv = nn.ModuleList(nn.Conv2d(in_channels, out_channels, 1) for _ in range(self.num_subset))
+        for conv in self.g_conv:
+            init_weights(conv, bs=self.num_subset)
+        if in_channels != out_channels:
+            self.gcn_residual = nn.Sequential(
+                nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels, momentum=bn_momentum)
+            )
+            init_weights(self.gcn_residual[0], bs=1)
+            init_weights(self.gcn_residual[1], bs=1)
+        else:
+            self.gcn_residual = unity
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum)
+        init_weights(self.bn, bs=1e-6)
+        self.relu = nn.ReLU()
+
+    def _fold(self):
+        return fold.fold_graph_conv(self.state_dict())
+
+    def forward(self, x):
+        self._require_eval()
+        _check_input(x, self.in_channels, "GraphConvolution input")
+        ops = self._packed_ops(x.device)
+        n, c, t, v = x.shape
+        if v != ops["V"]:
+            raise RuntimeError(f"input has V={v} joints, adjacency has {ops['V']}")
+        y = torch.empty((n, self.out_channels, t, v), device=x.device, dtype=torch.float32)
+        gcn_stage(x, y, ops, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v))
+        return y
+
+
+def gcn_stage(x, y, ops, n_seg, frames, x_strides, y_strides, adj_seg_stride=0):
+    rc = native.lib().csk_gcn_stage_f32(
+        native.ptr(x), native.ptr(y), native.ptr(ops["w"]), native.ptr(ops["bias"]),
+        native.ptr(ops["ell_src"]), native.ptr(ops["ell_val"]), native.ptr(ops["ell_cnt_host"]),
+        ops["ell_w"], adj_seg_stride, n_seg, ops["c_in"], ops["c_out"], frames, ops["V"],
+        x_strides[0], x_strides[1], y_strides[0], y_strides[1], ops["res_mode"], native.stream_of(x),
+    )
+    native.check(rc, "csk_gcn_stage_f32")
+
+
+# ---- models/base.py:279-304 -----------------------------------------------------------------------
+class TemporalConvolution(_Folded):
+    """Conv2d (k,1) stride (s,1) pad (p,0) + BatchNorm2d."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=9, stride=1, padding=4):
+        super().__init__()
+        self.padding = padding
+        self.stride = stride
+        self.kernel_size = kernel_size
+        self.t_conv = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(padding, 0),
+                                stride=(stride, 1))
+        self.bn = nn.BatchNorm2d(out_channels)
+        init_weights(self.t_conv, bs=1)
+        init_weights(self.bn, bs=1)
+
+    def _fold(self):
+        f = fold.fold_temporal_conv(self.state_dict())
+        f["bias"] = fold.pad_vec(f["bias"])
+        return f
+
+    def forward(self, x):
+        self._require_eval()
+        _check_input(x, self.t_conv.in_channels, "TemporalConvolution input")
+        ops = self._packed_ops(x.device)
+        return tcn_stage(x, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.padding, relu=False)
+
+
+def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=None, w_res=None, res_off=0):
+    n, c, t_in, v = y.shape
+    if t_in + 2 * pad < k:
+        raise RuntimeError(f"temporal extent {t_in} (+2*{pad}) shorter than kernel {k}")
+    t_out = (t_in + 2 * pad - k) // stride + 1
+    out = torch.empty((n, c_out, t_out, v), device=y.device, dtype=torch.float32)
+    c_res, t_res = (x_res.shape[1], x_res.shape[2]) if x_res is not None else (0, 0)
+    rc = native.lib().csk_tcn_stage_f32(
+        native.ptr(y), native.ptr(w), native.ptr(x_res), native.ptr(w_res), native.ptr(bias), native.ptr(out),
+        n, c, c_out, t_in, v, k, stride, pad, res_mode, c_res, t_res, res_off, int(relu), native.stream_of(y),
+    )
+    native.check(rc, "csk_tcn_stage_f32")
+    return out
+
+
+# ---- models/base.py:337-387 -----------------------------------------------------------------------
+class SpatioTemporalBlock(_Folded):
+    """ReLU(tcn(gcn(x)) + residual(x)); residual in {zero, identity, conv1x1(stride)+BN}; optional
+    centred residual shrink when ``temporal_padding`` is given (the "*" variants)."""
+
+    def __init__(self, in_channels, out_channels, A, stride=1, residual=True, temporal_kernel_size=9,
+                 temporal_padding=-1, GraphConv=GraphConvolution, TempConv=TemporalConvolution):
+        super().__init__()
+        equal_padding = int((temporal_kernel_size - 1) / 2)
+        if temporal_padding < 0:
+            temporal_padding = equal_padding
+            self.residual_shrink = None
+        else:
+            assert temporal_padding <= equal_padding
+            self.residual_shrink = equal_padding - temporal_padding
+        self.stride = stride
+        self.gcn = GraphConv(in_channels, out_channels, A)
+        self.tcn = TempConv(out_channels, out_channels, stride=stride, kernel_size=temporal_kernel_size,
+                            padding=temporal_padding)
+        self.relu = nn.ReLU()
+        if not residual:
+            self.residual = zero
+        elif (in_channels == out_channels) and (stride == 1):
+            self.residual = unity
+        else:
+            self.residual = TempConv(in_channels, out_channels, kernel_size=1, stride=stride, padding=0)
+        self._native_tail = isinstance(self.tcn, TemporalConvolution) and (
+            self.residual in (zero, unity) or isinstance(self.residual, TemporalConvolution)
+        )
+
+    def _fold(self):
+        sd = self.state_dict()
+        return fold.fold_block_tail(sd, "", has_conv_residual=isinstance(self.residual, TemporalConvolution))
+
+    def forward(self, x):
+        self._require_eval()
+        native.require_device_f32(x, "SpatioTemporalBlock input")
+        y = self.gcn(x)                                   # GCN stage kernel (or any user GraphConv module)
+        if not self._native_tail:
+            # foreign TempConv / residual modules: compose exactly as models/base.py:376-387
+            z = self.tcn(y)
+            r = self.residual(x[:, :, self.residual_shrink:-self.residual_shrink] if self.residual_shrink else x)
+            return self.relu(z + r)
+        ops = self._packed_ops(x.device)
+        shrink = self.residual_shrink or 0
+        if self.residual is zero:
+            mode, xr = 0, None
+        elif self.residual is unity:
+            mode, xr = 1, x
+        else:
+            mode, xr = 2, x
+        return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
+                         res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink)

@@ -1,0 +1,500 @@
+// stages.hip -- gfx950 (MI355X) kernels for the ST-GCN clip forward path.
+//
+// Two stage kernels per SpatioTemporalBlock, both built on one fp32-MFMA "shifted GEMM" core:
+//
+//   gcn_stage : y   = ReLU( W' . agg(x) + b' + gcn_residual(x) )          models/base.py:260-270
+//   tcn_stage : out = ReLU( W' . taps(y) + b' + block_residual(x) )        models/base.py:302-304,376-387
+//
+// GEMM view (per skeleton sequence = "segment"):  D[co, q] = sum_r sum_c W[r][c][co] * B_r[c][q]
+//   q  = flattened (frame, joint) position, V innermost  -> coalesced HBM rows, conflict-free LDS reads
+//   TCN: B_r[c][q] = y[c][q + (r - pad) * V]      -- a tap is an address shift inside one LDS tile
+//   GCN: B_r[c][q] = sum_v x[c][frame(q), v] * A_eff[r][v, joint(q)]   -- sparse (ELL) VALU gather
+//        into an LDS tile, adjacency tables staged in LDS
+// Arithmetic: exact fp32 (v_mfma_f32_32x32x2_f32), BatchNorm(eval)/biases folded into W'/b' on the host.
+//
+// Tiling: 256 threads = 4 waves, each wave owns a 64x64 output tile (2x2 MFMA 32x32 accumulators);
+// workgroup tile MT x NT with MT*NT = 16384 (64x256 for C_out = 64, 128x128 otherwise).  K loop walks
+// channel chunks of KC = 8; one activation chunk in LDS serves all 9 taps.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cskel.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int KC = CSK_KC;
+static constexpr int NTHREADS = 256;
+
+static thread_local char g_err[256] = "";
+#define CSK_FAIL(...)                                  \
+    do {                                               \
+        snprintf(g_err, sizeof(g_err), __VA_ARGS__);   \
+        return -1;                                     \
+    } while (0)
+
+extern "C" int csk_abi_version(void) { return CSK_ABI_VERSION; }
+extern "C" const char *csk_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// shared device pieces
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int div_magic(int x, unsigned magic) {
+    // x / V for 0 <= x < 2^32 / V, magic = ceil(2^32 / V): one v_mul_hi_u32
+    return (int)__umulhi((unsigned)x, magic);
+}
+
+// One K-chunk of the shifted GEMM for one wave: acc[mi][ni] += W[r][kk][rows] x B[r][kk][cols].
+//   Wl : [taps][KC][MT]  (row = output channel contiguous -> A operand, lane i = l&31, k = l>>5)
+//   Bl : B value of (tap r, channel kk, column) at Bl[r*tapB + kk*ldb + off_ni]
+template <int MT>
+__device__ __forceinline__ void mfma_chunk(const float *__restrict__ Wl, const float *__restrict__ Bl,
+                                           int taps, int ldb, int tapB, int offA, int off0, int off1,
+                                           int kh, f32x16 (&acc)[2][2]) {
+    for (int r = 0; r < taps; ++r) {
+        const float *wr = Wl + r * (KC * MT) + offA;
+        const float *br = Bl + r * tapB;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const int kk = 2 * s + kh;
+            const float a0 = wr[kk * MT];
+            const float a1 = wr[kk * MT + 32];
+            const float b0 = br[kk * ldb + off0];
+            const float b1 = br[kk * ldb + off1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
+// stage taps*KC rows of MT packed weights (global [taps][Cpad][Mpad]) into Wl [taps][KC][MT]
+template <int MT>
+__device__ __forceinline__ void load_w_chunk(float *__restrict__ Wl, const float *__restrict__ w, int taps,
+                                             int Cpad, int Mpad, int c0, int m0, int tid) {
+    constexpr int M4 = MT / 4;
+    const int n4 = taps * KC * M4;
+    for (int e = tid; e < n4; e += NTHREADS) {
+        const int row = e / M4, m4 = e % M4;       // powers of two
+        const int r = row / KC, kk = row % KC;
+        const float4 v = *reinterpret_cast<const float4 *>(w + ((size_t)(r * Cpad + c0 + kk) * Mpad + m0 + m4 * 4));
+        *reinterpret_cast<float4 *>(Wl + row * MT + m4 * 4) = v;
+    }
+}
+
+// stage KC channel rows x span positions of one segment into Bl [KC][ldb]; positions outside
+// [0, TV) and channels >= C read as zero (conv zero padding / channel padding)
+__device__ __forceinline__ void load_b_chunk(float *__restrict__ Bl, const float *__restrict__ seg_base, int C,
+                                             int64_t chan_stride, int TV, int c0, int pbase, int span, int ldb,
+                                             int wave, int lane) {
+    for (int kk = wave; kk < KC; kk += NTHREADS / 64) {
+        const int c = c0 + kk;
+        const float *src = seg_base + (int64_t)c * chan_stride;
+        const bool cv = c < C;
+        float *dst = Bl + kk * ldb;
+        for (int j = lane; j < span; j += 64) {
+            const int pp = pbase + j;
+            float v = 0.f;
+            if (cv && pp >= 0 && pp < TV) v = src[pp];
+            dst[j] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TCN stage
+// ------------------------------------------------------------------------------------------------
+struct TcnParams {
+    const float *y, *w, *xres, *wres, *bias;
+    float *out;
+    int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
+    int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
+    unsigned vmagic;
+};
+
+template <int MT>
+__global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) {
+    constexpr int NT = 16384 / MT;
+    constexpr int WM = MT / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem;
+    float *Bl = smem + p.K * KC * MT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int seg = blockIdx.y, m0 = blockIdx.z * MT, q0 = blockIdx.x * NT;
+    const int V = p.V, Q = p.Tout * V;
+    const int qend = min(q0 + NT, Q);
+    const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
+
+    int off[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+        const int t = div_magic(q, p.vmagic);
+        off[ni] = p.stride * (t - ta) * V + (q - t * V);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const int offA = wm * 64 + l31;
+    // ---- phase 1: k x 1 temporal conv over y
+    {
+        const int fa = p.stride * ta - p.pad;
+        const int span = (p.stride * (tb - ta) + p.K) * V;
+        const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V;
+        for (int c0 = 0; c0 < p.Cpad; c0 += KC) {
+            __syncthreads();
+            load_w_chunk<MT>(Wl, p.w, p.K, p.Cpad, p.Mpad, c0, m0, tid);
+            load_b_chunk(Bl, seg_base, p.C, (int64_t)p.Tin * V, p.Tin * V, c0, fa * V, span, p.ldb, wave, lane);
+            __syncthreads();
+            mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+        }
+    }
+    // ---- phase 2: 1x1 strided residual conv over the block input (models/base.py:372-374)
+    if (p.res_mode == CSK_RES_CONV) {
+        const int fa = p.stride * ta + p.res_off;
+        const int span = (p.stride * (tb - ta) + 1) * V;
+        const float *seg_base = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+        for (int c0 = 0; c0 < p.CresPad; c0 += KC) {
+            __syncthreads();
+            load_w_chunk<MT>(Wl, p.wres, 1, p.CresPad, p.Mpad, c0, m0, tid);
+            load_b_chunk(Bl, seg_base, p.Cres, (int64_t)p.Tres * V, p.Tres * V, c0, fa * V, span, p.ldb, wave, lane);
+            __syncthreads();
+            mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
+        }
+    }
+    // ---- epilogue: + bias (+ identity residual), ReLU, store.  C/D map: col = lane&31, row = (g&3)+8(g>>2)+4(lane>>5)
+    float *oseg = p.out + (int64_t)seg * p.Cout * Q;
+    const float *rseg = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = q0 + wn * 64 + ni * 32 + l31;
+        if (q >= Q) continue;
+        int qres = 0;
+        if (p.res_mode == CSK_RES_IDENTITY) {
+            const int t = div_magic(q, p.vmagic);
+            qres = (t * p.stride + p.res_off) * V + (q - t * V);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = m0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+                if (co < p.Cout) {
+                    float v = acc[mi][ni][g] + p.bias[co];
+                    if (p.res_mode == CSK_RES_IDENTITY) v += rseg[(int64_t)co * p.Tres * V + qres];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    oseg[(int64_t)co * Q + q] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GCN stage
+// ------------------------------------------------------------------------------------------------
+struct GcnParams {
+    const float *x, *w, *bias;
+    float *y;
+    const int32_t *ell_src;
+    const float *ell_val;
+    int ell_cnt[3];
+    int ell_w;
+    int64_t adj_seg_stride, x_seg_stride, x_chan_stride, y_seg_stride, y_chan_stride;
+    int Cin, CinPad, Cout, Mpad, frames, V, R, res_mode, ldb;
+    unsigned vmagic;
+};
+
+template <int MT>
+__global__ __launch_bounds__(NTHREADS) void gcn_stage_kernel(const GcnParams p) {
+    constexpr int NT = 16384 / MT;
+    constexpr int WM = MT / 64;
+    constexpr int TPC = NTHREADS / NT;   // threads per column in the aggregation pass (1 or 2)
+    constexpr int KPT = KC / TPC;        // channels per thread there
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int V = p.V, R = p.R, EW = p.ell_w;
+    float *Wl = smem;                          // [R][KC][MT]
+    float *Xa = Wl + R * KC * MT;              // [R][KC][NT]   aggregated operand
+    float *Bx = Xa + R * KC * NT;              // [KC][ldb]     raw x frames
+    float *Lv = Bx + KC * p.ldb;               // [3][V][EW]    adjacency values
+    int *Ls = reinterpret_cast<int *>(Lv + 3 * V * EW);   // [3][V][EW] adjacency row indices
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int seg = blockIdx.y, m0 = blockIdx.z * MT, q0 = blockIdx.x * NT;
+    const int Q = p.frames * V;
+    const int qend = min(q0 + NT, Q);
+    const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
+    const int span = (tb - ta + 1) * V;
+
+    // adjacency (fixed graph, or this segment's attention matrix) -> LDS, once per workgroup
+    {
+        const int n = 3 * V * EW;
+        const float *gv = p.ell_val + (int64_t)seg * p.adj_seg_stride;
+        const int32_t *gs = p.ell_src + (int64_t)seg * p.adj_seg_stride;
+        for (int e = tid; e < n; e += NTHREADS) {
+            Lv[e] = gv[e];
+            Ls[e] = gs[e];
+        }
+    }
+    // aggregation-pass coordinates of this thread: one column, KPT channels
+    const int aj = tid % NT, ak0 = (tid / NT) * KPT;
+    const int aq = min(q0 + aj, Q - 1);
+    const int at = div_magic(aq, p.vmagic);
+    const int aw = aq - at * V;
+    const int afb = (at - ta) * V;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const int offA = wm * 64 + l31;
+    const int off0 = wn * 64 + l31, off1 = off0 + 32;
+    const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
+
+    for (int c0 = 0; c0 < p.CinPad; c0 += KC) {
+        __syncthreads();
+        load_w_chunk<MT>(Wl, p.w, R, p.CinPad, p.Mpad, c0, m0, tid);
+        load_b_chunk(Bx, seg_base, p.Cin, p.x_chan_stride, Q, c0, ta * V, span, p.ldb, wave, lane);
+        __syncthreads();
+        // sparse adjacency aggregation: Xa[r][kk][j] = sum_e val * Bx[kk][frame(j) + src]
+        const float *bx = Bx + ak0 * p.ldb + afb;
+        for (int r = 0; r < 3; ++r) {
+            float s[KPT];
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) s[kk] = 0.f;
+            const int cnt = p.ell_cnt[r];
+            const int eb = (r * V + aw) * EW;
+            for (int e = 0; e < cnt; ++e) {
+                const int src = Ls[eb + e];
+                const float val = Lv[eb + e];
+#pragma unroll
+                for (int kk = 0; kk < KPT; ++kk) s[kk] = fmaf(val, bx[kk * p.ldb + src], s[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) Xa[(r * KC + ak0 + kk) * NT + aj] = s[kk];
+        }
+        if (R == 4) {   // conv gcn_residual rides the same GEMM as a 4th "subset" with identity adjacency
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) Xa[(3 * KC + ak0 + kk) * NT + aj] = bx[kk * p.ldb + aw];
+        }
+        __syncthreads();
+        mfma_chunk<MT>(Wl, Xa, R, NT, KC * NT, offA, off0, off1, kh, acc);
+    }
+
+    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = q0 + wn * 64 + ni * 32 + l31;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = m0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+                if (co < p.Cout) {
+                    float v = acc[mi][ni][g] + p.bias[co];
+                    if (p.res_mode == CSK_RES_IDENTITY) v += seg_base[(int64_t)co * p.x_chan_stride + q];
+                    oseg[(int64_t)co * p.y_chan_stride + q] = fmaxf(v, 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pre / post
+// ------------------------------------------------------------------------------------------------
+__global__ void input_norm_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                  const float *__restrict__ shift, float *__restrict__ h, int C, int T, int V, int M,
+                                  int64_t h_seg_stride, int64_t h_chan_stride, int64_t total) {
+    // one thread per input element, x index = (((n*C + c)*T + t)*V + v)*M + m  (reads fully coalesced)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int m = r % M; r /= M;
+        const int v = r % V; r /= V;
+        const int t = r % T; r /= T;
+        const int c = r % C;
+        const int64_t n = r / C;
+        const int ch = (m * V + v) * C + c;
+        h[(n * M + m) * h_seg_stride + (int64_t)c * h_chan_stride + (int64_t)t * V + v] = fmaf(x[i], scale[ch], shift[ch]);
+    }
+}
+
+// feat[n, c] = mean over m and over TV positions; one wave per (n, c)
+__global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ h, float *__restrict__ feat, int N, int M,
+                                                   int C, int TV) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // (n, c)
+    if (row >= (int64_t)N * C) return;
+    const int n = row / C, c = row % C;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float *src = h + ((int64_t)(n * M + m) * C + c) * TV;
+        for (int j = lane; j < TV; j += 64) s += src[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) feat[row] = s / (float)((int64_t)M * TV);
+}
+
+// logits[n, k] = feat[n] . fc_w[k] + fc_b[k]; one wave per output
+__global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ feat, const float *__restrict__ w,
+                                                 const float *__restrict__ b, float *__restrict__ logits, int N, int C,
+                                                 int classes) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + wave;
+    if (o >= (int64_t)N * classes) return;
+    const int n = o / classes, k = o % classes;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(feat[(int64_t)n * C + c], w[(int64_t)k * C + c], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) logits[o] = s + b[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+static inline unsigned vmagic_of(int V) { return (unsigned)(((1ull << 32) + V - 1) / V); }
+
+extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
+                                 const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,
+                                 int stride, int pad, int res_mode, int c_res, int t_res, int res_off, int relu,
+                                 void *stream) {
+    if (!y || !w || !bias || !out) CSK_FAIL("tcn_stage: null pointer");
+    if (n_seg <= 0 || c <= 0 || c_out <= 0 || t_in <= 0 || V < 2 || V > 64) CSK_FAIL("tcn_stage: bad dims");
+    if (k < 1 || k > 15 || stride < 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage: bad k/stride/pad");
+    if (t_in + 2 * pad < k) CSK_FAIL("tcn_stage: t_in too short for kernel");
+    const int t_out = (t_in + 2 * pad - k) / stride + 1;
+    if (res_mode != CSK_RES_NONE) {
+        if (!x_res) CSK_FAIL("tcn_stage: residual requested without x_res");
+        if (res_mode == CSK_RES_IDENTITY && c_res != c_out) CSK_FAIL("tcn_stage: identity residual needs c_res == c_out");
+        if (res_mode == CSK_RES_CONV && !w_res) CSK_FAIL("tcn_stage: conv residual without w_res");
+        if ((t_out - 1) * stride + res_off >= t_res || res_off < 0) CSK_FAIL("tcn_stage: residual frames out of range");
+    }
+    if ((int64_t)t_in * V >= (1 << 26)) CSK_FAIL("tcn_stage: T*V too large for 32-bit position arithmetic");
+    TcnParams p;
+    p.y = y; p.w = w; p.xres = x_res ? x_res : y; p.wres = w_res; p.bias = bias; p.out = out;
+    p.C = c; p.Cpad = round_up(c, KC); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.stride = stride; p.pad = pad;
+    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, KC);
+    p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
+    const bool big = (p.Mpad % 128) == 0;
+    const int MT = big ? 128 : 64, NT = 16384 / MT;
+    const int max_dt = (NT + V - 2) / V;
+    p.ldb = round_up((stride * max_dt + k) * V, 4);
+    const size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
+    if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
+    const int Q = t_out * V;
+    dim3 grid((Q + NT - 1) / NT, n_seg, p.Mpad / MT);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (big) {
+        e = hipFuncSetAttribute((const void *)tcn_stage_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(tcn_stage_kernel<128>, grid, dim3(NTHREADS), lds, s, p);
+    } else {
+        e = hipFuncSetAttribute((const void *)tcn_stage_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(tcn_stage_kernel<64>, grid, dim3(NTHREADS), lds, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
+                                 const float *ell_val, const int32_t *ell_cnt, int ell_w, int64_t adj_seg_stride,
+                                 int n_seg, int c_in, int c_out, int frames, int V, int64_t x_seg_stride,
+                                 int64_t x_chan_stride, int64_t y_seg_stride, int64_t y_chan_stride, int res_mode,
+                                 void *stream) {
+    if (!x || !y || !w || !bias || !ell_src || !ell_val || !ell_cnt) CSK_FAIL("gcn_stage: null pointer");
+    if (n_seg <= 0 || c_in <= 0 || c_out <= 0 || frames <= 0 || V < 2 || V > 64) CSK_FAIL("gcn_stage: bad dims");
+    if (ell_w < 1 || ell_w > V) CSK_FAIL("gcn_stage: ell_w must be in [1, V]");
+    if (res_mode != CSK_RES_IDENTITY && res_mode != CSK_RES_CONV) CSK_FAIL("gcn_stage: res_mode must be identity or conv");
+    if (res_mode == CSK_RES_IDENTITY && c_in != c_out) CSK_FAIL("gcn_stage: identity residual needs c_in == c_out");
+    GcnParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ell_src = ell_src; p.ell_val = ell_val;
+    for (int i = 0; i < 3; ++i) {
+        if (ell_cnt[i] < 0 || ell_cnt[i] > ell_w) CSK_FAIL("gcn_stage: ell_cnt[%d] out of range", i);
+        p.ell_cnt[i] = ell_cnt[i];
+    }
+    p.ell_w = ell_w; p.adj_seg_stride = adj_seg_stride;
+    p.x_seg_stride = x_seg_stride; p.x_chan_stride = x_chan_stride;
+    p.y_seg_stride = y_seg_stride; p.y_chan_stride = y_chan_stride;
+    p.Cin = c_in; p.CinPad = round_up(c_in, KC); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.frames = frames; p.V = V; p.R = res_mode == CSK_RES_CONV ? 4 : 3; p.res_mode = res_mode;
+    p.vmagic = vmagic_of(V);
+    const bool big = (p.Mpad % 128) == 0;
+    const int MT = big ? 128 : 64, NT = 16384 / MT;
+    const int max_dt = (NT + V - 2) / V;
+    p.ldb = round_up((max_dt + 1) * V, 4);
+    const size_t lds = (size_t)(p.R * KC * MT + p.R * KC * NT + KC * p.ldb + 2 * 3 * V * ell_w) * sizeof(float);
+    if (lds > 160 * 1024) CSK_FAIL("gcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
+    const int Q = frames * V;
+    if ((int64_t)frames * V >= (1 << 26)) CSK_FAIL("gcn_stage: frames*V too large for 32-bit position arithmetic");
+    dim3 grid((Q + NT - 1) / NT, n_seg, p.Mpad / MT);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (big) {
+        e = hipFuncSetAttribute((const void *)gcn_stage_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(gcn_stage_kernel<128>, grid, dim3(NTHREADS), lds, s, p);
+    } else {
+        e = hipFuncSetAttribute((const void *)gcn_stage_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(gcn_stage_kernel<64>, grid, dim3(NTHREADS), lds, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_input_norm_f32(const float *x, const float *scale, const float *shift, float *h, int N, int C,
+                                  int T, int V, int M, int64_t h_seg_stride, int64_t h_chan_stride, void *stream) {
+    if (!x || !scale || !shift || !h) CSK_FAIL("input_norm: null pointer");
+    if (N <= 0 || C <= 0 || T <= 0 || V <= 0 || M <= 0) CSK_FAIL("input_norm: bad dims");
+    const int64_t total = (int64_t)N * C * T * V * M;
+    const int64_t want = (total + 255) / 256;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(input_norm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift, h, C, T, V,
+                       M, h_seg_stride, h_chan_stride, total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *logits, int N, int C,
+                          int classes, void *stream) {
+    if (!feat || !fc_w || !fc_b || !logits) CSK_FAIL("fc: null pointer");
+    if (N <= 0 || C <= 0 || classes <= 0) CSK_FAIL("fc: bad dims");
+    const int64_t outs = (int64_t)N * classes;
+    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feat, fc_w, fc_b,
+                       logits, N, C, classes);
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_pool_fc_f32(const float *h, const float *fc_w, const float *fc_b, float *feat, float *logits, int N,
+                               int M, int C, int TV, int classes, void *stream) {
+    if (!h || !feat) CSK_FAIL("pool_fc: null pointer");
+    if (N <= 0 || M <= 0 || C <= 0 || TV <= 0) CSK_FAIL("pool_fc: bad dims");
+    const int64_t rows = (int64_t)N * C;
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, feat, N, M,
+                       C, TV);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (logits) return csk_fc_f32(feat, fc_w, fc_b, logits, N, C, classes, stream);
+    return 0;
+}

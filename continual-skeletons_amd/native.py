@@ -1,0 +1,78 @@
+"""ctypes binding of ``libcskel_hip.so`` (C ABI declared in ``include/cskel.h``).
+
+The product path has no fallback: if the library is missing, ``lib()`` raises with the build hint;
+if a call fails, ``check()`` raises with the library's own message.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
+ABI_VERSION = 1
+
+_p, _i, _l = C.c_void_p, C.c_int, C.c_int64
+# name -> argtypes; mirrors include/cskel.h line by line
+SIGNATURES = {
+    "csk_abi_version": [],
+    "csk_gcn_stage_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _p],
+    "csk_tcn_stage_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "csk_input_norm_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _p],
+    "csk_pool_fc_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "csk_fc_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP library is not built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        handle.csk_last_error.restype = C.c_char_p
+        handle.csk_last_error.argtypes = []
+        if handle.csk_abi_version() != ABI_VERSION:
+            raise RuntimeError("libcskel_hip.so ABI version mismatch; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {lib().csk_last_error().decode()}")
+    raise RuntimeError(f"{what}: HIP launch failed with hipError_t {rc}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_of(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_device_f32(t: torch.Tensor, name: str):
+    """The error convention of the boundary: wrong device/dtype/layout -> RuntimeError."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: this is the MI355X-native path and has no CPU fallback "
+            "(move the module and its inputs to a ROCm device)"
+        )
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")

@@ -1,0 +1,111 @@
+/*
+ * cskel.h -- C ABI of the MI355X-native ST-GCN / CoST-GCN forward path (libcskel_hip.so).
+ *
+ * The reference (LukasHedegaard/continual-skeletons) has no native code and no FFI: its hot path is
+ * the Python nn.Module surface of models/base.py issuing stock ATen ops.  Each entry point below
+ * replaces the ATen op sequence of one reference method (cited per function); the Python host layer
+ * in continual-skeletons_amd/ mirrors the reference's module interface and binds these with ctypes.
+ *
+ * Conventions
+ *  - all tensors fp32, device (HBM) pointers, laid out exactly as the reference's contiguous tensors:
+ *    clip activations (NM, C, T, V) with V innermost; "segment" = one of the NM skeleton sequences.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous,
+ *    no allocation and no synchronisation happens inside any call (graph-capture safe).
+ *  - packed weights are produced once on the host by continual-skeletons_amd/fold.py
+ *    (BatchNorm(eval) + bias folding, zero padding of channel counts to CSK_KC / CSK_MT multiples).
+ *  - return value: 0 = ok; <0 = argument error (see csk_last_error()); >0 = hipError_t of the launch.
+ */
+#ifndef CSKEL_H
+#define CSKEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSK_ABI_VERSION 1
+#define CSK_KC 8   /* channel-chunk of the K loop; packed weights pad C_in to a multiple of this   */
+#define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
+
+/* residual forms of SpatioTemporalBlock (models/base.py:367-374) and GraphConvolution (:246-254) */
+#define CSK_RES_NONE 0
+#define CSK_RES_IDENTITY 1
+#define CSK_RES_CONV 2
+
+int csk_abi_version(void);
+/* thread-local text of the last argument error */
+const char *csk_last_error(void);
+
+/*
+ * GraphConvolution.forward, models/base.py:260-270 (and its per-frame use by CoGraphConvolution,
+ * base.py:273-276):   y = ReLU( BN( sum_i W_i * (x .A_eff[i]) + b_i ) + gcn_residual(x) )
+ *
+ *  x        (n_seg, c_in, frames, V) with strides x_seg_stride / x_chan_stride (elements); frames
+ *           contiguous (V floats each).
+ *  y        (n_seg, c_out, frames, V), same convention.
+ *  w        packed [R][c_in_pad][c_out_pad]; R = 3 subsets (+1 = conv gcn_residual when
+ *           res_mode == CSK_RES_CONV); BN scale folded in.
+ *  bias     [c_out_pad] folded (conv biases, BN shift, and gcn_residual's BN shift).
+ *  ell_src  [3][V][ell_w] int32 : row indices v of the non-zeros of column w of A_eff[i] (padded with 0)
+ *  ell_val  [3][V][ell_w] fp32  : their values (padded with 0.0)
+ *  ell_cnt  [3] : number of meaningful entries per subset (<= ell_w) -- lets sparse subsets skip padding
+ *  adj_seg_stride: 0 for a graph shared by all segments (ST-GCN); 3*V*ell_w for per-segment
+ *           adjacency (A-GCN's per-sample attention, models/a_gcn/a_gcn.py:62-65).
+ *  res_mode CSK_RES_IDENTITY (c_in == c_out) or CSK_RES_CONV.
+ */
+int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias,
+                      const int32_t *ell_src, const float *ell_val, const int32_t *ell_cnt,
+                      int ell_w, int64_t adj_seg_stride,
+                      int n_seg, int c_in, int c_out, int frames, int V,
+                      int64_t x_seg_stride, int64_t x_chan_stride,
+                      int64_t y_seg_stride, int64_t y_chan_stride,
+                      int res_mode, void *stream);
+
+/*
+ * TemporalConvolution.forward (models/base.py:302-304) fused with the tail of
+ * SpatioTemporalBlock.forward (base.py:376-387):
+ *     out = ReLU( BN(conv_{k x 1, stride s, pad p}(y)) + residual(x[:, :, shrink:T-shrink]) )
+ * or, with relu == 0 and res_mode == NONE, a bare TemporalConvolution.
+ *
+ *  y        (n_seg, c, t_in, V) contiguous           -- output of the GCN stage
+ *  w        packed [k][c_pad][c_out_pad], BN scale folded
+ *  x_res    (n_seg, c_res, t_res, V) contiguous or NULL -- block input for the residual
+ *  w_res    packed [1][c_res_pad][c_out_pad] (CSK_RES_CONV) or NULL
+ *  bias     [c_out_pad] folded (t_conv bias, BN shift, residual conv bias + BN shift)
+ *  out      (n_seg, c_out, t_out, V), t_out = (t_in + 2p - k)/s + 1
+ *  res_off  frame offset of the residual: out[t'] pairs with x_res[t'*s + res_off]
+ *           (= residual_shrink, base.py:379-383; 0 when padded)
+ */
+int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
+                      const float *bias, float *out,
+                      int n_seg, int c, int c_out, int t_in, int V, int k, int stride, int pad,
+                      int res_mode, int c_res, int t_res, int res_off, int relu, void *stream);
+
+/*
+ * Input permute + data_bn + reshape, models/st_gcn/st_gcn.py:49-57 (clip) and
+ * models/base.py:73-82 (per frame, t = 1):
+ *     h[n*M+m, c, t, v] = x[n, c, t, v, m] * scale[(m*V+v)*C+c] + shift[(m*V+v)*C+c]
+ *  x (N, C, T, V, M) contiguous;  h (N*M, C, T, V) with strides h_seg_stride/h_chan_stride.
+ */
+int csk_input_norm_f32(const float *x, const float *scale, const float *shift, float *h,
+                       int N, int C, int T, int V, int M,
+                       int64_t h_seg_stride, int64_t h_chan_stride, void *stream);
+
+/*
+ * Head, models/st_gcn/st_gcn.py:60-64: feat[n, c] = mean_m mean_{t,v} h[n*M+m, c, t, v];
+ * logits = feat @ fc_w^T + fc_b.   h (N*M, C, TV) contiguous; feat (N, C) is also returned
+ * (it is the per-step feature of CoModelBase.spatial_pool, models/base.py:84).
+ *  fc_w (classes, C) row-major as in nn.Linear; logits (N, classes).  Pass logits == NULL to only pool.
+ */
+int csk_pool_fc_f32(const float *h, const float *fc_w, const float *fc_b, float *feat, float *logits,
+                    int N, int M, int C, int TV, int classes, void *stream);
+
+/* plain FC on pooled features: logits[n] = feat[n] @ fc_w^T + fc_b  (co.Linear, models/base.py:99) */
+int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *logits,
+               int N, int C, int classes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSKEL_H */

@@ -1,0 +1,133 @@
+"""GPU parity, clip path: HIP stage kernels (through the C ABI) vs golden vectors from the reference and
+vs the CPU oracle on seeded inputs.  Tolerance: |hip - ref| <= 1e-4 absolute on O(1) activations
+(BASELINE.json north_star: "within 1e-4 fp32")."""
+import numpy as np
+import pytest
+import torch
+
+import _bootstrap
+from oracle import stgcn_oracle as o
+from tests.helpers import g6_state_dict, load_golden, max_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+pkg = _bootstrap.load()
+DEV = "cuda:0"
+
+
+def _A(v=25):
+    return (pkg.ntu_graph() if v == 25 else pkg.kinetics_graph()).A
+
+
+@pytest.mark.parametrize("tag,ci,co", [("eq", 4, 4), ("neq", 3, 8)])
+def test_graph_conv_golden(tag, ci, co):
+    a, sd = load_golden(f"g1_gcn_{tag}")
+    m = pkg.GraphConvolution(ci, co, _A()).eval()
+    m.load_state_dict(sd, strict=True)
+    y = m.to(DEV)(torch.from_numpy(a["x"]).to(DEV))
+    assert max_err(y.cpu(), a["y"]) <= TOL
+
+
+@pytest.mark.parametrize("tag", ["k9s1p4", "k9s2p4", "k1s2p0", "k9s1p0"])
+def test_temporal_conv_golden(tag):
+    a, sd = load_golden(f"g2_tcn_{tag}")
+    k, s, p = (int(v) for v in a["meta"])
+    m = pkg.TemporalConvolution(4, 4, k, s, p).eval()
+    m.load_state_dict(sd, strict=True)
+    y = m.to(DEV)(torch.from_numpy(a["x"]).to(DEV))
+    assert tuple(y.shape) == a["y"].shape and max_err(y.cpu(), a["y"]) <= TOL
+
+
+@pytest.mark.parametrize("tag", ["nores", "ident", "convres", "strided", "nopad", "nopad_strided"])
+def test_block_golden(tag):
+    a, sd = load_golden(f"g3_block_{tag}")
+    ci, co, s, res, tp = (int(v) for v in a["meta"])
+    m = pkg.SpatioTemporalBlock(ci, co, _A(), s, bool(res), temporal_padding=tp).eval()
+    m.load_state_dict(sd, strict=True)
+    y = m.to(DEV)(torch.from_numpy(a["x"]).to(DEV))
+    assert tuple(y.shape) == a["y"].shape and max_err(y.cpu(), a["y"]) <= TOL
+
+
+def test_stack_golden():
+    a, sd = load_golden("g4_stack")
+    A = _A()
+    stack = torch.nn.Sequential(
+        pkg.SpatioTemporalBlock(3, 3, A, residual=False), pkg.SpatioTemporalBlock(3, 3, A),
+        pkg.SpatioTemporalBlock(3, 4, A, stride=2),
+    ).eval()
+    stack.load_state_dict(sd, strict=True)
+    y = stack.to(DEV)(torch.from_numpy(a["x"]).to(DEV))
+    assert max_err(y.cpu(), a["y"]) <= TOL
+
+
+def test_config1_block_golden():
+    """BASELINE config 1: SpatioTemporalBlock(3, 64, A_ntu, residual=False) on (2, 3, 300, 25)."""
+    from closed_form import closed_form_input
+
+    a, sd = load_golden("g5_config1_block")
+    m = pkg.SpatioTemporalBlock(3, 64, _A(), residual=False).eval()
+    m.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(closed_form_input((2, 3, 300, 25), salt=5.0)).to(DEV)
+    y = m.to(DEV)(x).cpu()
+    assert tuple(y.shape) == tuple(a["y_shape"])
+    assert max_err(y.reshape(-1)[::7], a["y_sub7"]) <= TOL
+    assert np.allclose(y.sum(dim=(0, 2, 3)).numpy(), a["y_chan_sum"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["ntu", "kin"])
+def test_full_stgcn_golden(tag):
+    a, sd, x = g6_state_dict(tag)
+    v, classes = (25, 60) if tag == "ntu" else (18, 400)
+    net = pkg.StGcn(_A(v), input_shape=(3, 300, v, 2), num_classes=classes).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    taps = {}
+    hooks = [net.layers[f"layer{i}"].register_forward_hook(lambda m, inp, out, i=i: taps.__setitem__(i, out))
+             for i in (1, 5, 8, 10)]
+    logits = net(x.to(DEV)).cpu()
+    for h in hooks:
+        h.remove()
+    for i in (1, 5, 8, 10):
+        assert max_err(taps[i].cpu().reshape(-1)[::997], a[f"layer{i}_sub"]) <= TOL, f"layer{i}"
+    assert max_err(logits, a["logits"]) <= TOL
+
+
+@pytest.mark.parametrize("ci,co,stride,res,T,N", [
+    (64, 64, 1, True, 37, 3),      # identity residual, ragged last tile
+    (64, 128, 2, True, 50, 2),     # strided conv residual, MT=128 path
+    (128, 256, 2, True, 31, 2),    # odd T with stride 2, two M tiles
+    (3, 64, 1, False, 300, 1),     # layer-1 shape
+    (20, 12, 1, True, 9, 1),       # channel counts that are not multiples of the tile sizes
+])
+def test_block_vs_oracle_seeded(ci, co, stride, res, T, N):
+    torch.manual_seed(1234 + ci + co + T)
+    m = pkg.SpatioTemporalBlock(ci, co, _A(), stride, res).eval()
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("graph_attn") or name.endswith("bn.weight") or name.endswith("residual.1.weight"):
+                prm.copy_(torch.rand_like(prm) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand_like(prm) - 0.5)
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand_like(buf) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand_like(buf) - 0.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.rand(N, ci, T, 25)
+    with torch.no_grad():
+        want = o.st_block(x, sd, "", stride, res)
+    got = m.to(DEV)(x.to(DEV)).cpu()
+    scale = max(1.0, float(want.abs().max()))
+    assert got.shape == want.shape and max_err(got, want) <= TOL * scale
+
+
+def test_errors_are_loud():
+    m = pkg.SpatioTemporalBlock(4, 4, _A())
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m.to(DEV)(torch.rand(1, 4, 20, 25, device=DEV))
+    m.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 4, 20, 25))
+    with pytest.raises(RuntimeError):
+        m.to(DEV)(torch.rand(1, 4, 20, 25, device=DEV).double())
