@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X-native ST-GCN / CoST-GCN forward path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload clip|step] [--batch B]
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  clip : full 10-block ST-GCN clip forward (input norm -> 10 blocks -> pool+fc), batch 256 clips per GPU,
+         NTU-60 shape (3, 300, 25, 2), fp32                                  [BASELINE.json configs[1]]
+  step : CoST-GCN online inference, one new frame for each of 1024 concurrent streams per GPU, persistent
+         ring-buffer state in HBM                                              [BASELINE.json configs[2]]
+Multi-GPU (torchrun, one process per GPU): the batch / stream axis is sharded (weak scaling: per-GPU work is
+fixed), the only exchange is one RCCL all-gather of logits per step.  Rank 0 prints ONE JSON line.
+
+`roofline` is computed for the dominant kernel (tcn_stage_kernel: 9x1 temporal conv + BN + residual + ReLU,
+70 % of the path's FLOPs): algorithmic FLOPs of its launches (SURVEY 8d accounting) / their duration measured
+live with HIP events on the launch stream, against the dense fp32 MFMA peak (157.3 TFLOP/s).
+`cpu_baseline` times the CPU oracle (a port of the reference's op sequence, see oracle/) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32)
+NTU = dict(C=3, T=300, V=25, M=2, classes=60)
+
+
+def randomise_(net, seed):
+    """Random-init weights of the named architecture with non-trivial BN statistics (data: synthetic)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in net.named_parameters():
+            if name.endswith("graph_attn"):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif "bn" in name and name.endswith("weight"):
+                prm.copy_(torch.rand(prm.shape, generator=g) * 0.5 + 0.25)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand(prm.shape, generator=g) * 0.2 - 0.1)
+        for name, buf in net.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand(buf.shape, generator=g) * 0.2 - 0.1)
+
+
+class LaunchTimer:
+    """HIP-event timing of every launch of one stage, on the stream the kernels are launched on."""
+
+    def __init__(self, pkg, name):
+        self.pkg, self.name, self.orig = pkg, name, getattr(pkg.blocks, name)
+        self.records, self.enabled = [], False
+
+    def __enter__(self):
+        def wrapped(*a, **k):
+            if not self.enabled:
+                return self.orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(*a, **k)
+            e1.record()
+            self.records.append((e0, e1))
+            return out
+        setattr(self.pkg.blocks, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.pkg.blocks, self.name, self.orig)
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.records)
+
+
+def tcn_flops_per_clip_forward(nm, c_in=3, T=300, V=25):
+    """Algorithmic FLOPs of the ten tcn_stage launches for nm skeleton sequences (TCN 9x1 +
+    block-residual 1x1 MACs, 2 FLOP per MAC)."""
+    from oracle.stgcn_oracle import layer_table
+    t, macs = T, 0
+    for (ci, co, s, res) in layer_table(c_in):
+        t_out = (t + 8 - 9) // s + 1
+        per_pos = 9 * co * co + (ci * co if (res and (ci != co or s != 1)) else 0)
+        macs += per_pos * t_out * V
+        t = t_out
+    return 2 * macs * nm
+
+
+def cpu_baseline_clip(seed, threads):
+    """Oracle (CPU port of the reference op sequence) on a bounded sample: 8 clips x up to 3 passes."""
+    from oracle import stgcn_oracle as o
+    import _bootstrap
+    pkg = _bootstrap.load()
+    torch.set_num_threads(threads)
+    net = pkg.StGcn(pkg.ntu_graph().A).eval()
+    randomise_(net, seed)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.rand((8, NTU["C"], NTU["T"], NTU["V"], NTU["M"]), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        o.stgcn_forward(x[:1], sd)                      # warm-up
+        t0, n = time.perf_counter(), 0
+        while n < 3 and (time.perf_counter() - t0) < 20.0:
+            o.stgcn_forward(x, sd)
+            n += 1
+        dt = time.perf_counter() - t0
+    return dict(value=round(8 * n / dt, 3), unit="clips/s", cores=threads, kind="port",
+                sample=f"{n} passes of 8 NTU-60 clips (batch 8) through oracle.stgcn_forward, torch CPU fp32")
+
+
+def load_traffic():
+    """Per-launch HBM bytes of the dominant kernel from the committed PMC summary (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic_tcn_stage.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="clip", choices=["clip"])
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import _bootstrap
+    pkg = _bootstrap.load()
+    from continual_skeletons_amd import parallel
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_clip(seed=0, threads=os.cpu_count() or 1)
+
+    B = args.batch
+    net = pkg.StGcn(pkg.ntu_graph().A, input_shape=(NTU["C"], NTU["T"], NTU["V"], NTU["M"]), num_classes=NTU["classes"]).eval()
+    randomise_(net, seed=0)                              # identical weights on every rank
+    net = net.to(dev)
+    x = torch.rand((B, NTU["C"], NTU["T"], NTU["V"], NTU["M"]), device=dev,
+                   generator=torch.Generator(device=dev).manual_seed(100 + rank))
+
+    def step():
+        logits = net(x)
+        return parallel.all_gather_logits(logits) if world > 1 else logits
+
+    with LaunchTimer(pkg, "tcn_stage") as lt:
+        for _ in range(args.warmup):
+            out = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lt.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lt.enabled = False
+        tcn_ms = lt.total_ms()
+        n_launch = len(lt.records)
+
+    assert out.shape == (B * world, NTU["classes"]) and bool(torch.isfinite(out).all())
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        clips = B * world * args.steps
+        flops_launch = tcn_flops_per_clip_forward(B * NTU["M"]) / 10.0       # average over the 10 launches / step
+        avg_launch_s = tcn_ms / 1e3 / max(1, n_launch)
+        achieved = flops_launch / avg_launch_s / 1e12
+        traffic = load_traffic()
+        line = {
+            "metric": "clips/sec (ST-GCN clip forward, NTU-60 shape; CoST-GCN online step reported separately)",
+            "value": round(clips / dt, 2),
+            "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ST-GCN 10-block clip forward, batch {B}/GPU, NTU-60 (3,300,25,2), fp32 [configs[1]]",
+                       "global_batch": B * world, "frames_per_clip": NTU["T"], "parallelism": f"batch-shard x{world}",
+                       "skeleton_frames_per_s": round(clips / dt * NTU["T"], 1)},
+            "roofline": {"bound": "mfma", "kernel": "tcn_stage_kernel", "achieved": round(achieved, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches_timed": n_launch,
+                         "flops_per_launch": flops_launch,
+                         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""world_size-2 gloo tests of the batch-shard + logit all-gather path (runs on CPU)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _bootstrap
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = _bootstrap.load()
+    from continual_skeletons_amd import parallel
+    full = torch.arange(n_total * 5, dtype=torch.float32).view(n_total, 5)   # "logits" every rank can recompute
+    lo, hi = parallel.shard_bounds(n_total, rank, world)
+    got = parallel.all_gather_ragged(full[lo:hi].clone(), n_total)
+    ok = torch.equal(got, full)
+    if n_total % world == 0:
+        ok = ok and torch.equal(parallel.all_gather_logits(full[lo:hi].clone()), full)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def _run(n_total):
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: True, 1: True}
+
+
+def test_shard_bounds_cover_and_partition():
+    pkg = _bootstrap.load()
+    from continual_skeletons_amd import parallel
+    for n, w in [(8192, 8), (10, 3), (7, 8), (1, 2)]:
+        b = [parallel.shard_bounds(n, r, w) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_all_gather_even_world2():
+    _run(8)
+
+
+def test_all_gather_ragged_world2():
+    _run(7)
