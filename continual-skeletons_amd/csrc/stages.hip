@@ -23,6 +23,7 @@
 #include "../../include/cskel.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP float4 is a struct)
 
 static constexpr int KC = CSK_KC;
 static constexpr int NTHREADS = 256;
@@ -70,38 +71,86 @@ __device__ __forceinline__ void mfma_chunk(const float *__restrict__ Wl, const f
     }
 }
 
-// stage taps*KC rows of MT packed weights (global [taps][Cpad][Mpad]) into Wl [taps][KC][MT]
+// ---- staging, split into ISSUE (global -> registers) and COMMIT (registers -> LDS) so that the loads of
+// chunk i+1 are in flight underneath the MFMAs of chunk i (register prefetch; the commit happens behind the
+// barrier that retires chunk i's LDS reads).
+// No predication anywhere (a predicated element makes hipcc branch around each load, wait vmcnt(0) per
+// element and demote the array to scratch): out-of-range slots are CLAMPED to the last valid element, so
+// surplus threads reload / rewrite the same value to the same address.  Per-thread offsets are chunk
+// invariant and computed once; the per-chunk part of every address is wave-uniform (scalar base).
 template <int MT>
-__device__ __forceinline__ void load_w_chunk(float *__restrict__ Wl, const float *__restrict__ w, int taps,
-                                             int Cpad, int Mpad, int c0, int m0, int tid) {
-    constexpr int M4 = MT / 4;
-    const int n4 = taps * KC * M4;
-    for (int e = tid; e < n4; e += NTHREADS) {
-        const int row = e / M4, m4 = e % M4;       // powers of two
-        const int r = row / KC, kk = row % KC;
-        const float4 v = *reinterpret_cast<const float4 *>(w + ((size_t)(r * Cpad + c0 + kk) * Mpad + m0 + m4 * 4));
-        *reinterpret_cast<float4 *>(Wl + row * MT + m4 * 4) = v;
-    }
-}
-
-// stage KC channel rows x span positions of one segment into Bl [KC][ldb]; positions outside
-// [0, TV) and channels >= C read as zero (conv zero padding / channel padding)
-__device__ __forceinline__ void load_b_chunk(float *__restrict__ Bl, const float *__restrict__ seg_base, int C,
-                                             int64_t chan_stride, int TV, int c0, int pbase, int span, int ldb,
-                                             int wave, int lane) {
-    for (int kk = wave; kk < KC; kk += NTHREADS / 64) {
-        const int c = c0 + kk;
-        const float *src = seg_base + (int64_t)c * chan_stride;
-        const bool cv = c < C;
-        float *dst = Bl + kk * ldb;
-        for (int j = lane; j < span; j += 64) {
-            const int pp = pbase + j;
-            float v = 0.f;
-            if (cv && pp >= 0 && pp < TV) v = src[pp];
-            dst[j] = v;
+struct WStage {
+    static constexpr int M4 = MT / 4;
+    static constexpr int WB = (9 * KC * M4 + NTHREADS - 1) / NTHREADS;   // f32x4 per thread for a 9-tap chunk
+    unsigned goff[WB];   // element offset inside a chunk of packed weights (global [taps][Cpad][Mpad])
+    unsigned loff[WB];   // element offset inside Wl [taps][KC][MT]
+    f32x4 v[WB];
+    __device__ __forceinline__ void setup(int taps, int Cpad, int Mpad, int tid) {
+        const int last = taps * KC * M4 - 1;
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+            const int e = min(u * NTHREADS + tid, last);
+            const int row = e / M4, m4 = e % M4;   // powers of two
+            goff[u] = (unsigned)(((row / KC) * Cpad + (row % KC)) * Mpad + m4 * 4);
+            loff[u] = (unsigned)(e * 4);
         }
     }
-}
+    // chunk_base = w + c0 * Mpad + m0 (uniform)
+    __device__ __forceinline__ void issue(const float *__restrict__ chunk_base) {
+#pragma unroll
+        for (int u = 0; u < WB; ++u) v[u] = *reinterpret_cast<const f32x4 *>(chunk_base + goff[u]);
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Wl) const {
+#pragma unroll
+        for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(Wl + loff[u]) = v[u];
+    }
+};
+
+// activations: KC channel rows x span positions of one segment -> Bl [KC][ldb]; positions outside [0, TV)
+// and channels >= C read as zero (conv zero padding / channel padding): the address is clamped into the
+// tensor and the value replaced by 0 with a select, so the load itself is unconditional.
+template <int NJ>
+struct BStage {
+    static constexpr int RPW = KC / (NTHREADS / 64);   // rows per wave
+    unsigned goff[NJ];   // clamped position inside a channel row
+    unsigned loff[NJ];   // position inside an LDS row
+    unsigned valid;      // bit u: position is inside [0, TV)
+    float v[RPW][NJ];
+    __device__ __forceinline__ void setup(int pbase, int span, int TV, int lane) {
+        valid = 0;
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            const int j = min(u * 64 + lane, span - 1);
+            const int pp = pbase + j;
+            goff[u] = (unsigned)min(max(pp, 0), TV - 1);
+            loff[u] = (unsigned)j;
+            valid |= (pp >= 0 && pp < TV) ? (1u << u) : 0u;
+        }
+    }
+    // wave is wave-uniform (readfirstlane); rows c0 + wave + 4*rr
+    __device__ __forceinline__ void issue(const float *__restrict__ seg_base, int C, int64_t chan_stride, int c0,
+                                          int wave) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int c = c0 + wave + rr * (NTHREADS / 64);
+            const float *src = seg_base + (int64_t)min(c, C - 1) * chan_stride;
+            const unsigned m = c < C ? valid : 0u;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                const float x = src[goff[u]];
+                v[rr][u] = ((m >> u) & 1u) ? x : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Bl, int ldb, int wave) const {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            float *dst = Bl + (wave + rr * (NTHREADS / 64)) * ldb;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) dst[loff[u]] = v[rr][u];
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // TCN stage
@@ -114,7 +163,7 @@ struct TcnParams {
     unsigned vmagic;
 };
 
-template <int MT>
+template <int MT, int NJ>
 __global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) {
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
@@ -122,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) 
     float *Wl = smem;
     float *Bl = smem + p.K * KC * MT;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
     const int seg = blockIdx.y, m0 = blockIdx.z * MT, q0 = blockIdx.x * NT;
@@ -147,16 +196,28 @@ __global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) 
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
     const int offA = wm * 64 + l31;
+    WStage<MT> ws;
+    BStage<NJ> bs;
     // ---- phase 1: k x 1 temporal conv over y
     {
         const int fa = p.stride * ta - p.pad;
         const int span = (p.stride * (tb - ta) + p.K) * V;
         const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V;
+        const int64_t cs = (int64_t)p.Tin * V;
+        const float *wbase = p.w + m0;
+        ws.setup(p.K, p.Cpad, p.Mpad, tid);
+        bs.setup(fa * V, span, p.Tin * V, lane);
+        ws.issue(wbase);
+        bs.issue(seg_base, p.C, cs, 0, wave);
         for (int c0 = 0; c0 < p.Cpad; c0 += KC) {
+            __syncthreads();                       // previous chunk's LDS reads are done
+            ws.commit(Wl);
+            bs.commit(Bl, p.ldb, wave);
             __syncthreads();
-            load_w_chunk<MT>(Wl, p.w, p.K, p.Cpad, p.Mpad, c0, m0, tid);
-            load_b_chunk(Bl, seg_base, p.C, (int64_t)p.Tin * V, p.Tin * V, c0, fa * V, span, p.ldb, wave, lane);
-            __syncthreads();
+            if (c0 + KC < p.Cpad) {                // next chunk's loads fly underneath the MFMAs below
+                ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
+                bs.issue(seg_base, p.C, cs, c0 + KC, wave);
+            }
             mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
         }
     }
@@ -165,11 +226,21 @@ __global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) 
         const int fa = p.stride * ta + p.res_off;
         const int span = (p.stride * (tb - ta) + 1) * V;
         const float *seg_base = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+        const int64_t cs = (int64_t)p.Tres * V;
+        const float *wbase = p.wres + m0;
+        ws.setup(1, p.CresPad, p.Mpad, tid);
+        bs.setup(fa * V, span, p.Tres * V, lane);
+        ws.issue(wbase);
+        bs.issue(seg_base, p.Cres, cs, 0, wave);
         for (int c0 = 0; c0 < p.CresPad; c0 += KC) {
             __syncthreads();
-            load_w_chunk<MT>(Wl, p.wres, 1, p.CresPad, p.Mpad, c0, m0, tid);
-            load_b_chunk(Bl, seg_base, p.Cres, (int64_t)p.Tres * V, p.Tres * V, c0, fa * V, span, p.ldb, wave, lane);
+            ws.commit(Wl);
+            bs.commit(Bl, p.ldb, wave);
             __syncthreads();
+            if (c0 + KC < p.CresPad) {
+                ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
+                bs.issue(seg_base, p.Cres, cs, c0 + KC, wave);
+            }
             mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
         }
     }
@@ -216,7 +287,7 @@ struct GcnParams {
     unsigned vmagic;
 };
 
-template <int MT>
+template <int MT, int NJ>
 __global__ __launch_bounds__(NTHREADS) void gcn_stage_kernel(const GcnParams p) {
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
@@ -230,7 +301,7 @@ __global__ __launch_bounds__(NTHREADS) void gcn_stage_kernel(const GcnParams p) 
     float *Lv = Bx + KC * p.ldb;               // [3][V][EW]    adjacency values
     int *Ls = reinterpret_cast<int *>(Lv + 3 * V * EW);   // [3][V][EW] adjacency row indices
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
     const int seg = blockIdx.y, m0 = blockIdx.z * MT, q0 = blockIdx.x * NT;
@@ -268,11 +339,22 @@ __global__ __launch_bounds__(NTHREADS) void gcn_stage_kernel(const GcnParams p) 
     const int off0 = wn * 64 + l31, off1 = off0 + 32;
     const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
 
+    WStage<MT> ws;
+    BStage<NJ> bs;
+    const float *wbase = p.w + m0;
+    ws.setup(R, p.CinPad, p.Mpad, tid);
+    bs.setup(ta * V, span, Q, lane);
+    ws.issue(wbase);
+    bs.issue(seg_base, p.Cin, p.x_chan_stride, 0, wave);
     for (int c0 = 0; c0 < p.CinPad; c0 += KC) {
+        __syncthreads();                           // previous chunk's MFMA reads of Wl / Xa are done
+        ws.commit(Wl);
+        bs.commit(Bx, p.ldb, wave);
         __syncthreads();
-        load_w_chunk<MT>(Wl, p.w, R, p.CinPad, p.Mpad, c0, m0, tid);
-        load_b_chunk(Bx, seg_base, p.Cin, p.x_chan_stride, Q, c0, ta * V, span, p.ldb, wave, lane);
-        __syncthreads();
+        if (c0 + KC < p.CinPad) {                  // prefetch the next chunk underneath aggregation + MFMA
+            ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
+            bs.issue(seg_base, p.Cin, p.x_chan_stride, c0 + KC, wave);
+        }
         // sparse adjacency aggregation: Xa[r][kk][j] = sum_e val * Bx[kk][frame(j) + src]
         const float *bx = Bx + ak0 * p.ldb + afb;
         for (int r = 0; r < 3; ++r) {
@@ -373,6 +455,17 @@ __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ feat,
 // C ABI
 // ------------------------------------------------------------------------------------------------
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// pick the <MT, NJ> instantiation, raise its dynamic-LDS cap, launch
+template <typename P, typename K>
+static int launch_stage(bool big, bool small_span, dim3 grid, size_t lds, hipStream_t s, const P &p, K k128a, K k128b,
+                        K k64a, K k64b) {
+    K k = big ? (small_span ? k128a : k128b) : (small_span ? k64a : k64b);
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds, s, p);
+    return (int)hipGetLastError();
+}
 static inline unsigned vmagic_of(int V) { return (unsigned)(((1ull << 32) + V - 1) / V); }
 
 extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
@@ -381,7 +474,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
                                  void *stream) {
     if (!y || !w || !bias || !out) CSK_FAIL("tcn_stage: null pointer");
     if (n_seg <= 0 || c <= 0 || c_out <= 0 || t_in <= 0 || V < 2 || V > 64) CSK_FAIL("tcn_stage: bad dims");
-    if (k < 1 || k > 15 || stride < 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage: bad k/stride/pad");
+    if (k < 1 || k > 9 || stride < 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage: bad k/stride/pad (k <= 9)");
     if (t_in + 2 * pad < k) CSK_FAIL("tcn_stage: t_in too short for kernel");
     const int t_out = (t_in + 2 * pad - k) / stride + 1;
     if (res_mode != CSK_RES_NONE) {
@@ -405,18 +498,10 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = t_out * V;
     dim3 grid((Q + NT - 1) / NT, n_seg, p.Mpad / MT);
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (big) {
-        e = hipFuncSetAttribute((const void *)tcn_stage_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(tcn_stage_kernel<128>, grid, dim3(NTHREADS), lds, s, p);
-    } else {
-        e = hipFuncSetAttribute((const void *)tcn_stage_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(tcn_stage_kernel<64>, grid, dim3(NTHREADS), lds, s, p);
-    }
-    return (int)hipGetLastError();
+    const int nj = (p.ldb + 63) / 64;
+    if (nj > 14) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
+    return launch_stage(big, nj <= 9, grid, lds, (hipStream_t)stream, p,
+                        tcn_stage_kernel<128, 9>, tcn_stage_kernel<128, 14>, tcn_stage_kernel<64, 9>, tcn_stage_kernel<64, 14>);
 }
 
 extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
@@ -450,18 +535,10 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     const int Q = frames * V;
     if ((int64_t)frames * V >= (1 << 26)) CSK_FAIL("gcn_stage: frames*V too large for 32-bit position arithmetic");
     dim3 grid((Q + NT - 1) / NT, n_seg, p.Mpad / MT);
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (big) {
-        e = hipFuncSetAttribute((const void *)gcn_stage_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(gcn_stage_kernel<128>, grid, dim3(NTHREADS), lds, s, p);
-    } else {
-        e = hipFuncSetAttribute((const void *)gcn_stage_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(gcn_stage_kernel<64>, grid, dim3(NTHREADS), lds, s, p);
-    }
-    return (int)hipGetLastError();
+    const int nj = (p.ldb + 63) / 64;
+    if (nj > 14) CSK_FAIL("gcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
+    return launch_stage(big, nj <= 9, grid, lds, (hipStream_t)stream, p,
+                        gcn_stage_kernel<128, 9>, gcn_stage_kernel<128, 14>, gcn_stage_kernel<64, 9>, gcn_stage_kernel<64, 14>);
 }
 
 extern "C" int csk_input_norm_f32(const float *x, const float *scale, const float *shift, float *h, int N, int C,
