@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/cskel.h"
 
@@ -53,21 +54,39 @@ template <int MT>
 __device__ __forceinline__ void mfma_chunk(const float *__restrict__ Wl, const float *__restrict__ Bl,
                                            int taps, int ldb, int tapB, int offA, int off0, int off1,
                                            int kh, f32x16 (&acc)[2][2]) {
+    // Fragment reads run one k-step ahead of the MFMAs that consume them (the wait for step s+1's operands
+    // then sits behind the four 64-cycle MFMAs of step s instead of in front of them).
+    const float *wr = Wl + offA + kh * MT;
+    const float *br = Bl + kh * ldb;
+    float a0 = wr[0], a1 = wr[32], b0 = br[off0], b1 = br[off1];
     for (int r = 0; r < taps; ++r) {
-        const float *wr = Wl + r * (KC * MT) + offA;
-        const float *br = Bl + r * tapB;
+        const int rn = min(r + 1, taps - 1);            // last iteration re-reads its own tap (harmless)
+        const float *wn = Wl + rn * (KC * MT) + offA + kh * MT;
+        const float *bn = Bl + rn * tapB + kh * ldb;
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
-            const int kk = 2 * s + kh;
-            const float a0 = wr[kk * MT];
-            const float a1 = wr[kk * MT + 32];
-            const float b0 = br[kk * ldb + off0];
-            const float b1 = br[kk * ldb + off1];
+            float na0, na1, nb0, nb1;
+            if (s + 1 < KC / 2) {
+                na0 = wr[(2 * s + 2) * MT];
+                na1 = wr[(2 * s + 2) * MT + 32];
+                nb0 = br[(2 * s + 2) * ldb + off0];
+                nb1 = br[(2 * s + 2) * ldb + off1];
+            } else {
+                na0 = wn[0];
+                na1 = wn[32];
+                nb0 = bn[off0];
+                nb1 = bn[off1];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next step's ds_reads ABOVE this step's MFMAs
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
+        wr = wn;
+        br = bn;
     }
 }
 
@@ -161,10 +180,11 @@ struct TcnParams {
     int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
     int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
     unsigned vmagic;
+    int debug;   // TEMP ablation bits
 };
 
 template <int MT, int NJ>
-__global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams p) {
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -210,11 +230,14 @@ __global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) 
         ws.issue(wbase);
         bs.issue(seg_base, p.C, cs, 0, wave);
         for (int c0 = 0; c0 < p.Cpad; c0 += KC) {
-            __syncthreads();                       // previous chunk's LDS reads are done
+            const bool first = c0 == 0;
+            if (first || !(p.debug & 4)) __syncthreads();                       // previous chunk's LDS reads are done
+            if (first || !(p.debug & 1)) {
             ws.commit(Wl);
             bs.commit(Bl, p.ldb, wave);
-            __syncthreads();
-            if (c0 + KC < p.Cpad) {                // next chunk's loads fly underneath the MFMAs below
+            }
+            if (first || !(p.debug & 4)) __syncthreads();
+            if (c0 + KC < p.Cpad && !(p.debug & 2)) {                // next chunk's loads fly underneath the MFMAs below
                 ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
                 bs.issue(seg_base, p.C, cs, c0 + KC, wave);
             }
@@ -245,28 +268,38 @@ __global__ __launch_bounds__(NTHREADS) void tcn_stage_kernel(const TcnParams p) 
         }
     }
     // ---- epilogue: + bias (+ identity residual), ReLU, store.  C/D map: col = lane&31, row = (g&3)+8(g>>2)+4(lane>>5)
+    // Loads are unconditional (clamped indices; bias is padded to Mpad) and batched 16 deep; only the stores
+    // are predicated.
     float *oseg = p.out + (int64_t)seg * p.Cout * Q;
     const float *rseg = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+    const int64_t rcs = (int64_t)p.Tres * V;
+    const bool ident = p.res_mode == CSK_RES_IDENTITY;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int q = q0 + wn * 64 + ni * 32 + l31;
-        if (q >= Q) continue;
+        const bool qv = q < Q;
+        const int qc = min(q, Q - 1);
         int qres = 0;
-        if (p.res_mode == CSK_RES_IDENTITY) {
-            const int t = div_magic(q, p.vmagic);
-            qres = (t * p.stride + p.res_off) * V + (q - t * V);
+        if (ident) {
+            const int t = div_magic(qc, p.vmagic);
+            qres = (t * p.stride + p.res_off) * V + (qc - t * V);
         }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
+            float bv[16], rv[16];
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int co = m0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
-                if (co < p.Cout) {
-                    float v = acc[mi][ni][g] + p.bias[co];
-                    if (p.res_mode == CSK_RES_IDENTITY) v += rseg[(int64_t)co * p.Tres * V + qres];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    oseg[(int64_t)co * Q + q] = v;
-                }
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                bv[g] = p.bias[co];
+                rv[g] = ident ? rseg[(int64_t)min(co, p.Cout - 1) * rcs + qres] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                float v = acc[mi][ni][g] + bv[g] + rv[g];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (qv && co < p.Cout) oseg[(int64_t)co * Q + q] = v;
             }
         }
     }
@@ -288,7 +321,7 @@ struct GcnParams {
 };
 
 template <int MT, int NJ>
-__global__ __launch_bounds__(NTHREADS) void gcn_stage_kernel(const GcnParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams p) {
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
     constexpr int TPC = NTHREADS / NT;   // threads per column in the aggregation pass (1 or 2)
@@ -381,20 +414,27 @@ __global__ __launch_bounds__(NTHREADS) void gcn_stage_kernel(const GcnParams p) 
     }
 
     float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+    const bool ident = p.res_mode == CSK_RES_IDENTITY;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int q = q0 + wn * 64 + ni * 32 + l31;
-        if (q >= Q) continue;
+        const bool qv = q < Q;
+        const int qc = min(q, Q - 1);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
+            float bv[16], rv[16];
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int co = m0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
-                if (co < p.Cout) {
-                    float v = acc[mi][ni][g] + p.bias[co];
-                    if (p.res_mode == CSK_RES_IDENTITY) v += seg_base[(int64_t)co * p.x_chan_stride + q];
-                    oseg[(int64_t)co * p.y_chan_stride + q] = fmaxf(v, 0.f);
-                }
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                bv[g] = p.bias[co];
+                rv[g] = ident ? seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                const float v = fmaxf(acc[mi][ni][g] + bv[g] + rv[g], 0.f);
+                if (qv && co < p.Cout) oseg[(int64_t)co * p.y_chan_stride + q] = v;
             }
         }
     }
@@ -490,6 +530,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.stride = stride; p.pad = pad;
     p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, KC);
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
+    { const char *d = getenv("CSK_DEBUG"); p.debug = d ? atoi(d) : 0; }
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const int max_dt = (NT + V - 2) / V;
