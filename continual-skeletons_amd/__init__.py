@@ -19,14 +19,22 @@ from .blocks import (  # noqa: F401
     zero,
 )
 from .models import StGcn  # noqa: F401
+from .continual import (  # noqa: F401
+    CoGraphConvolution,
+    CoSpatioTemporalBlock,
+    CoStGcn,
+    CoTemporalConvolution,
+)
 from . import native  # noqa: F401
 
 # names used by BASELINE.json:north_star
 SpatialGraphConv = GraphConvolution
 StGcnBlock = SpatioTemporalBlock
+CoStGcnBlock = CoSpatioTemporalBlock
 
 __all__ = [
     "Graph", "ntu_graph", "kinetics_graph", "GraphConvolution", "TemporalConvolution",
-    "SpatioTemporalBlock", "SpatialGraphConv", "StGcnBlock", "StGcn", "init_weights", "zero", "unity",
+    "SpatioTemporalBlock", "SpatialGraphConv", "StGcnBlock", "CoStGcnBlock", "StGcn", "CoStGcn",
+    "CoGraphConvolution", "CoTemporalConvolution", "CoSpatioTemporalBlock", "init_weights", "zero", "unity",
     "native",
 ]

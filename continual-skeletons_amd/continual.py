@@ -1,0 +1,457 @@
+"""Continual (frame-by-frame) block library and the CoST-GCN step driver.
+
+Counterpart of the reference's ``CoGraphConvolution`` / ``CoTemporalConvolution`` /
+``CoSpatioTemporalBlock`` (models/base.py:273-276, 307-334, 390-446), ``CoModelBase`` (base.py:19-227)
+and ``CoStGcn`` (models/cost_gcn/cost_gcn.py).  In the reference the step arithmetic lives in the
+third-party ``continual-inference`` package (per-module Python-side buffers, one small ATen op per
+module per frame); here every block owns a slice of a persistent HBM state slab and a step is two
+kernel launches (csk_gcn_stage_f32 on the new frame, csk_tcn_step_f32 over the ring).
+
+Protocol (anchored on the reference's tests, see oracle/stgcn_oracle.py:CoBlockOracle):
+  * ``forward_step(x_t)`` -> output frame or ``None``; nothing is emitted during the first
+    ``delay = k-1-padding`` steps, and with temporal stride S only every S-th step emits;
+  * the emission of step s equals the clip block's output at t = (s - delay) / S;
+  * ``forward_steps(x, pad_end)``: all frames, optionally flushed with ``padding`` zero post-GCN frames;
+  * ``clean_state()`` zeroes the window (zero state == the clip conv's left zero padding).
+State layout (channel-major, see include/cskel.h): per block a y ring [k][C_out][P] and an output ring
+[5][C_out][P]; the output ring of block l is the input/residual history of block l+1, so the
+residual FIFO (``co.Delay``) costs no copy.
+"""
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import fold, native
+from .blocks import (GraphConvolution, SpatioTemporalBlock, TemporalConvolution, _Folded, gcn_stage,
+                     init_weights, unity, zero)
+from .models import layer_table
+
+HIST = 5     # depth of an input / output history ring: residual lag (k-1)/2 = 4 frames + the new one
+
+
+def _round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def CoGraphConvolution(in_channels, out_channels, A, bn_momentum=0.1):
+    """models/base.py:273-276 -- the per-frame graph conv is stateless, so it is the same module."""
+    return GraphConvolution(in_channels, out_channels, A, bn_momentum)
+
+
+class CoTemporalConvolution(TemporalConvolution):
+    """models/base.py:307-334: (k,1) conv + BN with a (k-1)-frame window.  ``padding="equal"`` -> (k-1)/2.
+    Note the reference's argument order (kernel_size, padding, stride) differs from TemporalConvolution's."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=9, padding=0, stride=1):
+        if padding == "equal":
+            padding = int((kernel_size - 1) / 2)
+        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.receptive_field = kernel_size
+        self.delay = kernel_size - 1 - padding
+        self._ring = None
+        self._s = 0
+
+    # -- continual interface on (N, C, V) frames -------------------------------------------------
+    def clean_state(self):
+        self._ring, self._s = None, 0
+
+    def _state(self, n, v, device):
+        p = _round4(n * v)
+        c = self.t_conv.in_channels
+        if self._ring is None or self._ring.shape != (self.kernel_size, c, p) or self._ring.device != device:
+            self._ring = torch.zeros((self.kernel_size, c, p), device=device, dtype=torch.float32)
+            self._s = 0
+        return p
+
+    def _emit(self, n, v, p):
+        ops = self._packed_ops(self._ring.device)
+        out = torch.empty((ops["c_out"], p), device=self._ring.device, dtype=torch.float32)
+        rc = native.lib().csk_tcn_step_f32(
+            native.ptr(self._ring), self.kernel_size, self._s % self.kernel_size, native.ptr(ops["w"]), None, None,
+            native.ptr(ops["bias"]), native.ptr(out), ops["c_in"], ops["c_out"], p, self.kernel_size, 0, 0, 0,
+            native.stream_of(out))
+        native.check(rc, "csk_tcn_step_f32")
+        return out[:, : n * v].view(-1, n, v).permute(1, 0, 2).contiguous()
+
+    def forward_step(self, x_t, update_state=True):
+        self._require_eval()
+        native.require_device_f32(x_t, "CoTemporalConvolution frame")
+        if not update_state:
+            raise NotImplementedError("update_state=False is not supported on the persistent-state path")
+        n, c, v = x_t.shape
+        p = self._state(n, v, x_t.device)
+        self._ring[self._s % self.kernel_size, :, : n * v] = x_t.permute(1, 0, 2).reshape(c, n * v)
+        s = self._s
+        out = None
+        if s >= self.delay and (s - self.delay) % self.stride == 0:
+            out = self._emit(n, v, p)
+        self._s += 1
+        return out
+
+    def forward_steps(self, x, pad_end=False, update_state=True):
+        n, c, t, v = x.shape
+        outs = [o for o in (self.forward_step(x[:, :, i].contiguous()) for i in range(t)) if o is not None]
+        if pad_end:
+            p = self._state(n, v, x.device)
+            for _ in range(self.padding):
+                self._ring[self._s % self.kernel_size].zero_()
+                if self._s >= self.delay and (self._s - self.delay) % self.stride == 0:
+                    outs.append(self._emit(n, v, p))
+                self._s += 1
+        return torch.stack(outs, dim=2)
+
+
+class _BlockState:
+    """Slice of the state slab owned by one block: y ring, output ring, (optionally own) input ring, counters."""
+
+    def __init__(self, c_in, c_out, k, p, device, xin=None):
+        self.p = p
+        self.y = torch.zeros((k, c_out, p), device=device, dtype=torch.float32)
+        self.out = torch.zeros((HIST, c_out, p), device=device, dtype=torch.float32)
+        self.owns_xin = xin is None
+        self.xin = torch.zeros((HIST, c_in, p), device=device, dtype=torch.float32) if xin is None else xin
+        self.s = 0      # frames received
+        self.e = 0      # frames emitted
+
+    def zero_(self):
+        self.y.zero_()
+        self.out.zero_()
+        if self.owns_xin:
+            self.xin.zero_()
+        self.s = self.e = 0
+
+    def nbytes(self):
+        return 4 * (self.y.numel() + self.out.numel() + (self.xin.numel() if self.owns_xin else 0))
+
+
+class CoSpatioTemporalBlock(SpatioTemporalBlock):
+    """models/base.py:390-446.  Same call signature as the reference's factory function; ``forward`` is the
+    clip computation (== SpatioTemporalBlock with ``temporal_padding=padding``), ``forward_step`` /
+    ``forward_steps`` run on the persistent state.
+
+    state_dict layout = the reference's container layout (tests/test_cost_gcn.py:97-98,145,193-198):
+    no residual -> ``gcn.* / tcn.*``; identity -> ``0.1.gcn.* / 0.1.tcn.*``; conv residual ->
+    ``0.0.residual.*`` + ``0.1.gcn.* / 0.1.tcn.*``.  The plain SpatioTemporalBlock layout also loads.
+    """
+
+    def __init__(self, in_channels, out_channels, A, stride=1, residual=True, window_size=1, padding=0,
+                 CoGraphConv=CoGraphConvolution, CoTempConv=None):
+        if padding == "equal":
+            padding = 4
+        window_size = int(window_size)  # unused by the reference as well (base.py:401)
+
+        def graph_conv(ci, co, a):
+            return CoGraphConv(ci, co, a, bn_momentum=0.1)
+
+        def temp_conv(ci, co, kernel_size=9, stride=1, padding=0):
+            if CoTempConv is None:
+                return TemporalConvolution(ci, co, kernel_size=kernel_size, stride=stride, padding=padding)
+            return CoTempConv(ci, co, kernel_size=kernel_size, padding=padding, stride=stride)
+
+        super().__init__(in_channels, out_channels, A, stride=stride, residual=residual, temporal_kernel_size=9,
+                         temporal_padding=padding, GraphConv=graph_conv, TempConv=temp_conv)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = 9
+        self.padding = padding
+        self.receptive_field = self.kernel_size
+        self.delay = self.kernel_size - 1 - padding
+        self.kind = "none" if self.residual is zero else ("identity" if self.residual is unity else "conv")
+        self._prefix_map = {"none": {}, "identity": {"gcn.": "0.1.gcn.", "tcn.": "0.1.tcn."},
+                            "conv": {"gcn.": "0.1.gcn.", "tcn.": "0.1.tcn.", "residual.": "0.0.residual."}}[self.kind]
+        self._state: Optional[_BlockState] = None
+        self._register_state_dict_hook(CoSpatioTemporalBlock._to_co_keys)
+        self._register_load_state_dict_pre_hook(self._from_co_keys)
+        if not (isinstance(self.gcn, GraphConvolution) and self._native_tail):
+            raise NotImplementedError("continual blocks need the native GraphConvolution / TemporalConvolution")
+
+    # ---- state_dict key layout -------------------------------------------------------------------
+    @staticmethod
+    def _to_co_keys(module, state_dict, prefix, local_metadata):
+        for plain, co in module._prefix_map.items():
+            for k in [k for k in state_dict if k.startswith(prefix + plain)]:
+                state_dict[prefix + co + k[len(prefix + plain):]] = state_dict.pop(k)
+        return state_dict
+
+    def _from_co_keys(self, state_dict, prefix, *args):
+        for plain, co in self._prefix_map.items():
+            for k in [k for k in state_dict if k.startswith(prefix + co)]:
+                state_dict[prefix + plain + k[len(prefix + co):]] = state_dict.pop(k)
+
+    def _fold(self):                      # fold from the PLAIN layout whatever state_dict() emits
+        sd = {}
+        for k, v in nn.Module.state_dict(self).items():
+            for plain, co in self._prefix_map.items():
+                if k.startswith(co):
+                    k = plain + k[len(co):]
+                    break
+            sd[k] = v
+        return fold.fold_block_tail(sd, "", has_conv_residual=self.kind == "conv")
+
+    # ---- persistent state --------------------------------------------------------------------------
+    def bind_state(self, p: int, device, xin: Optional[torch.Tensor] = None) -> _BlockState:
+        """(Re)allocate this block's slab slice for P positions; ``xin`` = upstream block's output ring."""
+        self._state = _BlockState(self.in_channels, self.out_channels, self.kernel_size, p, device, xin)
+        return self._state
+
+    def clean_state(self):
+        if self._state is not None:
+            self._state.zero_()
+
+    def engine_step(self, n_frames: int, V: int, flush: bool = False) -> Optional[int]:
+        """Advance by one frame that is already in ``xin[s % HIST]`` (channel-major).  Returns the slot of
+        the output ring that received this step's emission, or None.  ``flush`` pushes a zero post-GCN
+        frame instead (end padding)."""
+        st, k = self._state, self.kernel_size
+        s = st.s
+        y_slot = st.y[s % k]
+        if flush:
+            y_slot.zero_()
+        else:
+            gops = self.gcn._packed_ops(y_slot.device)
+            gcn_stage(st.xin[s % HIST], y_slot, gops, n_seg=1, frames=n_frames, x_strides=(0, st.p), y_strides=(0, st.p))
+        slot = None
+        if s >= self.delay and (s - self.delay) % self.stride == 0:
+            ops = self._packed_ops(y_slot.device)
+            lag = (k - 1) // 2          # emission s pairs with input frame s - 4 (co.Delay / residual_shrink)
+            mode = {"none": 0, "identity": 1, "conv": 2}[self.kind]
+            xres = st.xin[(s - lag) % HIST] if mode else None
+            slot = st.e % HIST
+            rc = native.lib().csk_tcn_step_f32(
+                native.ptr(st.y), k, s % k, native.ptr(ops["w"]), native.ptr(xres), native.ptr(ops["w_res"]),
+                native.ptr(ops["bias"]), native.ptr(st.out[slot]), self.out_channels, self.out_channels, st.p, k,
+                mode, self.in_channels if mode else 0, 1, native.stream_of(st.y))
+            native.check(rc, "csk_tcn_step_f32")
+            st.e += 1
+        st.s += 1
+        return slot
+
+    # ---- continual interface on (N, C, V) frames (module boundary: converts layouts) ------------
+    def _ensure_state(self, n, v, device):
+        p = _round4(n * v)
+        if self._state is None or self._state.p != p or self._state.y.device != device or not self._state.owns_xin:
+            self.bind_state(p, device)
+        return self._state
+
+    def forward_step(self, x_t, update_state=True):
+        self._require_eval()
+        native.require_device_f32(x_t, "CoSpatioTemporalBlock frame")
+        if not update_state:
+            raise NotImplementedError("update_state=False is not supported on the persistent-state path")
+        n, c, v = x_t.shape
+        if c != self.in_channels:
+            raise RuntimeError(f"expected (N, {self.in_channels}, V) frame, got {tuple(x_t.shape)}")
+        st = self._ensure_state(n, v, x_t.device)
+        st.xin[st.s % HIST, :, : n * v] = x_t.permute(1, 0, 2).reshape(c, n * v)
+        slot = self.engine_step(n, v)
+        if slot is None:
+            return None
+        return st.out[slot, :, : n * v].view(self.out_channels, n, v).permute(1, 0, 2).contiguous()
+
+    def forward_steps(self, x, pad_end=False, update_state=True):
+        n, c, t, v = x.shape
+        outs = [o for o in (self.forward_step(x[:, :, i].contiguous()) for i in range(t)) if o is not None]
+        if pad_end:
+            st = self._state
+            for _ in range(self.padding):
+                slot = self.engine_step(n, v, flush=True)
+                if slot is not None:
+                    outs.append(st.out[slot, :, : n * v].view(self.out_channels, n, v).permute(1, 0, 2).contiguous())
+        return torch.stack(outs, dim=2)
+
+
+def co_geometry(c_in=3):
+    """receptive_field / padding / stride of the ten-block stack (read from co.Sequential at base.py:86-97)."""
+    r, p, s = 1, 0, 1
+    for (_, _, st, _) in layer_table(c_in):
+        r += 8 * s
+        p += 4 * s
+        s *= st
+    return r, p, s
+
+
+class CoStGcn(_Folded):
+    """CoST-GCN: models/cost_gcn/cost_gcn.py:21-41 + CoModelBase (models/base.py:68-227) without the Ride shell.
+
+    ``forward_step(x_t: (N, C, V, M))`` -> logits (N, classes) on the steps where the whole stack (10 blocks,
+    total stride 4) and the temporal average pool emit, else None.  ``forward_steps(x: (N, C, T, V, M))``
+    -> (N, classes, n_predictions).  ``forward(x)`` = clip mode of CoModelBase.forward (base.py:166-181).
+    state_dict keys equal the reference's (``layers.layerK.0.1.gcn...``); a regular StGcn state_dict loads too
+    (what ``map_state_dict`` does in the reference, base.py:200-224).
+    """
+
+    def __init__(self, graph_A, input_shape=(3, 300, 25, 2), num_classes=60, pool_size=-1, pool_padding=-1):
+        super().__init__()
+        (c_in, t, v, m) = input_shape
+        self.input_shape, self.num_classes = tuple(input_shape), num_classes
+        self.data_bn = nn.BatchNorm1d(m * c_in * v)
+        self.layers = nn.ModuleDict(OrderedDict(
+            (f"layer{i + 1}", CoSpatioTemporalBlock(ci, co, graph_A, stride=s, residual=r, padding="equal"))
+            for i, (ci, co, s, r) in enumerate(layer_table(c_in))))
+        self.fc = nn.Linear(256, num_classes)
+        init_weights(self.data_bn, bs=1)
+        init_weights(self.fc, bs=num_classes)
+        self.receptive_field, self.padding, self.stride = co_geometry(c_in)
+        self.delay = self.padding
+        if pool_size == -1:                                                   # base.py:86-90
+            pool_size = math.ceil((t - self.receptive_field + 2 * self.padding + 1) / self.stride)
+        if pool_padding == -1:                                                # base.py:92-96
+            pool_padding = pool_size - math.ceil((t - self.receptive_field + self.padding + 1) / self.stride)
+        self.pool_size, self.pool_padding = pool_size, max(0, pool_padding)
+        self._n = None
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def map_state_dict(self, state_dict, strict=True):
+        """Regular-layout keys -> this module's (reference Co) layout (models/base.py:200-224)."""
+        own = nn.Module.state_dict(self).keys()
+
+        def short(k):
+            return k.replace("0.1.", "").replace("0.0.residual", "residual")
+        short2long = {short(k): k for k in own}
+        return OrderedDict((short2long[k], v) for k, v in state_dict.items() if strict or k in short2long)
+
+    def _fold(self):
+        s, t = fold.fold_data_bn({k: v for k, v in nn.Module.state_dict(self).items() if k.startswith("data_bn.")})
+        return dict(scale=s, shift=t)
+
+    def _fingerprint(self):
+        ts = list(self.data_bn.parameters()) + list(self.data_bn.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    # ---- state slab --------------------------------------------------------------------------------
+    def _bind(self, n, device):
+        c_in, _, v, m = self.input_shape
+        p = _round4(n * m * v)
+        xin = torch.zeros((HIST, c_in, p), device=device, dtype=torch.float32)
+        self._xin0, self._p, self._n = xin, p, n
+        for i in range(10):
+            st = self.layers[f"layer{i + 1}"].bind_state(p, device, xin)
+            xin = st.out
+        self._pool_ring = torch.zeros((self.pool_size, n, 256), device=device, dtype=torch.float32)
+        self._pooled = torch.empty((n, 256), device=device, dtype=torch.float32)
+        self._frames = self._feats = 0
+
+    def state_bytes(self):
+        return sum(self.layers[f"layer{i + 1}"]._state.nbytes() for i in range(10)) + 4 * (
+            self._xin0.numel() + self._pool_ring.numel())
+
+    def clean_state(self):
+        if self._n is not None:
+            self._xin0.zero_()
+            for i in range(10):
+                self.layers[f"layer{i + 1}"].clean_state()
+            self._pool_ring.zero_()
+            self._frames = self._feats = 0
+
+    # ---- stepping ------------------------------------------------------------------------------------
+    def features_step(self, x_t):
+        """(N, C, V, M) frame -> slot of layer 10's output ring holding this step's emission, or None."""
+        self._require_eval()
+        native.require_device_f32(x_t, "CoStGcn frame")
+        n, c, v, m = x_t.shape
+        if (c, v, m) != (self.input_shape[0], self.input_shape[2], self.input_shape[3]):
+            raise RuntimeError(f"frame shape {tuple(x_t.shape)} does not match input_shape {self.input_shape}")
+        if self._n != n or self._xin0.device != x_t.device:          # clean_state_on_shape_change (base.py:161-164)
+            self._bind(n, x_t.device)
+        ops = self._packed_ops(x_t.device)
+        dst = self._xin0[self._frames % HIST]
+        # reshape1 + data_bn + reshape2 (base.py:73-82) straight into the channel-major input ring
+        rc = native.lib().csk_input_norm_f32(native.ptr(x_t), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
+                                             native.ptr(dst), n, c, 1, v, m, v, self._p, native.stream_of(x_t))
+        native.check(rc, "csk_input_norm_f32")
+        self._frames += 1
+        slot = None
+        for i in range(10):
+            slot = self.layers[f"layer{i + 1}"].engine_step(n * m, v)
+            if slot is None:
+                return None
+        return slot
+
+    def _head_step(self, slot, n):
+        """spatial_pool -> co.AvgPool1d window -> co.Linear (base.py:84-101)."""
+        _, _, v, m = self.input_shape
+        st10 = self.layers["layer10"]._state
+        lib = native.lib()
+        head = self._feats % self.pool_size
+        stream = native.stream_of(st10.out)
+        native.check(lib.csk_co_spatial_pool_f32(native.ptr(st10.out[slot]), native.ptr(self._pool_ring[head]), n, 256,
+                                                 m * v, self._p, stream), "csk_co_spatial_pool_f32")
+        self._feats += 1
+        if self._feats < self.pool_size - self.pool_padding:
+            return None
+        count = min(self._feats, self.pool_size)
+        native.check(lib.csk_co_window_mean_f32(native.ptr(self._pool_ring), native.ptr(self._pooled), n * 256,
+                                                self.pool_size, head, count, stream), "csk_co_window_mean_f32")
+        logits = torch.empty((n, self.num_classes), device=st10.out.device, dtype=torch.float32)
+        native.check(lib.csk_fc_f32(native.ptr(self._pooled), native.ptr(self.fc.weight.detach()),
+                                    native.ptr(self.fc.bias.detach()), native.ptr(logits), n, 256, self.num_classes,
+                                    stream), "csk_fc_f32")
+        return logits
+
+    def forward_step(self, x_t, update_state=True):
+        if not update_state:
+            raise NotImplementedError("update_state=False is not supported on the persistent-state path")
+        slot = self.features_step(x_t)
+        return None if slot is None else self._head_step(slot, x_t.shape[0])
+
+    def forward_steps(self, x, pad_end=False, update_state=True):
+        """(N, C, T, V, M) -> (N, classes, n_predictions) (empty last dim if nothing was emitted)."""
+        if pad_end:
+            raise NotImplementedError("model-level pad_end is not used by the reference (base.py:177)")
+        outs = []
+        for t in range(x.shape[2]):
+            o = self.forward_step(x[:, :, t].contiguous())
+            if o is not None:
+                outs.append(o)
+        if not outs:
+            return torch.empty((x.shape[0], self.num_classes, 0), device=x.device)
+        return torch.stack(outs, dim=2)
+
+    def forward(self, x, forward_mode="clip"):
+        """CoModelBase.forward (base.py:166-181).  'clip': whole-clip computation with the continual head
+        (zero-padded temporal average pool, first window); 'frame': stepping with a fresh state."""
+        self._require_eval()
+        if forward_mode == "frame":
+            self.clean_state()
+            ret = self.forward_steps(x)
+            return ret[:, :, 0]
+        n, c, t, v, m = x.shape
+        h = self._clip_features(x)                                        # (N*M, 256, T', V)
+        tp = h.shape[2]
+        # spatial_pool per frame, then AvgPool1d(pool_size, stride 1, padding) output index 0:
+        # frames [0, pool_size - pool_padding) summed, divided by pool_size (zeros included)
+        take = min(tp, self.pool_size - self.pool_padding)
+        feat = torch.empty((n, 256), device=x.device, dtype=torch.float32)
+        hs = h[:, :, :take].contiguous()
+        rc = native.lib().csk_pool_fc_f32(native.ptr(hs), None, None, native.ptr(feat), None, n, m, 256, take * v, 0,
+                                          native.stream_of(x))
+        native.check(rc, "csk_pool_fc_f32")
+        feat = feat * (take / self.pool_size)
+        logits = torch.empty((n, self.num_classes), device=x.device, dtype=torch.float32)
+        native.check(native.lib().csk_fc_f32(native.ptr(feat), native.ptr(self.fc.weight.detach()),
+                                             native.ptr(self.fc.bias.detach()), native.ptr(logits), n, 256,
+                                             self.num_classes, native.stream_of(x)), "csk_fc_f32")
+        return logits
+
+    def _clip_features(self, x):
+        native.require_device_f32(x, "CoStGcn input")
+        n, c, t, v, m = x.shape
+        ops = self._packed_ops(x.device)
+        h = torch.empty((n * m, c, t, v), device=x.device, dtype=torch.float32)
+        rc = native.lib().csk_input_norm_f32(native.ptr(x), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
+                                             native.ptr(h), n, c, t, v, m, c * t * v, t * v, native.stream_of(x))
+        native.check(rc, "csk_input_norm_f32")
+        for i in range(10):
+            h = SpatioTemporalBlock.forward(self.layers[f"layer{i + 1}"], h)
+        return h
+
+    def warm_up(self, n, device, frames=None):
+        """Feed ``receptive_field - padding - 1`` random frames (models/base.py:144-159) so that the next
+        frame produces layer-10 output."""
+        self.clean_state()
+        c, _, v, m = self.input_shape
+        frames = self.receptive_field - self.padding - 1 if frames is None else frames
+        for _ in range(frames):
+            self.forward_step(torch.randn((n, c, v, m), device=device))

@@ -15,161 +15,15 @@
 // Tiling: 256 threads = 4 waves, each wave owns a 64x64 output tile (2x2 MFMA 32x32 accumulators);
 // workgroup tile MT x NT with MT*NT = 16384 (64x256 for C_out = 64, 128x128 otherwise).  K loop walks
 // channel chunks of KC = 8; one activation chunk in LDS serves all 9 taps.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
 #include <stdlib.h>
+#include <string.h>
 
-#include "../../include/cskel.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP float4 is a struct)
-
-static constexpr int KC = CSK_KC;
-static constexpr int NTHREADS = 256;
+#include "mfma_core.h"
 
 static thread_local char g_err[256] = "";
-#define CSK_FAIL(...)                                  \
-    do {                                               \
-        snprintf(g_err, sizeof(g_err), __VA_ARGS__);   \
-        return -1;                                     \
-    } while (0)
-
+char *csk_err_buf() { return g_err; }
 extern "C" int csk_abi_version(void) { return CSK_ABI_VERSION; }
 extern "C" const char *csk_last_error(void) { return g_err; }
-
-// ------------------------------------------------------------------------------------------------
-// shared device pieces
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int div_magic(int x, unsigned magic) {
-    // x / V for 0 <= x < 2^32 / V, magic = ceil(2^32 / V): one v_mul_hi_u32
-    return (int)__umulhi((unsigned)x, magic);
-}
-
-// One K-chunk of the shifted GEMM for one wave: acc[mi][ni] += W[r][kk][rows] x B[r][kk][cols].
-//   Wl : [taps][KC][MT]  (row = output channel contiguous -> A operand, lane i = l&31, k = l>>5)
-//   Bl : B value of (tap r, channel kk, column) at Bl[r*tapB + kk*ldb + off_ni]
-template <int MT>
-__device__ __forceinline__ void mfma_chunk(const float *__restrict__ Wl, const float *__restrict__ Bl,
-                                           int taps, int ldb, int tapB, int offA, int off0, int off1,
-                                           int kh, f32x16 (&acc)[2][2]) {
-    // Fragment reads run one k-step ahead of the MFMAs that consume them (the wait for step s+1's operands
-    // then sits behind the four 64-cycle MFMAs of step s instead of in front of them).
-    const float *wr = Wl + offA + kh * MT;
-    const float *br = Bl + kh * ldb;
-    float a0 = wr[0], a1 = wr[32], b0 = br[off0], b1 = br[off1];
-    for (int r = 0; r < taps; ++r) {
-        const int rn = min(r + 1, taps - 1);            // last iteration re-reads its own tap (harmless)
-        const float *wn = Wl + rn * (KC * MT) + offA + kh * MT;
-        const float *bn = Bl + rn * tapB + kh * ldb;
-#pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
-            float na0, na1, nb0, nb1;
-            if (s + 1 < KC / 2) {
-                na0 = wr[(2 * s + 2) * MT];
-                na1 = wr[(2 * s + 2) * MT + 32];
-                nb0 = br[(2 * s + 2) * ldb + off0];
-                nb1 = br[(2 * s + 2) * ldb + off1];
-            } else {
-                na0 = wn[0];
-                na1 = wn[32];
-                nb0 = bn[off0];
-                nb1 = bn[off1];
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the next step's ds_reads ABOVE this step's MFMAs
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-        }
-        wr = wn;
-        br = bn;
-    }
-}
-
-// ---- staging, split into ISSUE (global -> registers) and COMMIT (registers -> LDS) so that the loads of
-// chunk i+1 are in flight underneath the MFMAs of chunk i (register prefetch; the commit happens behind the
-// barrier that retires chunk i's LDS reads).
-// No predication anywhere (a predicated element makes hipcc branch around each load, wait vmcnt(0) per
-// element and demote the array to scratch): out-of-range slots are CLAMPED to the last valid element, so
-// surplus threads reload / rewrite the same value to the same address.  Per-thread offsets are chunk
-// invariant and computed once; the per-chunk part of every address is wave-uniform (scalar base).
-template <int MT>
-struct WStage {
-    static constexpr int M4 = MT / 4;
-    static constexpr int WB = (9 * KC * M4 + NTHREADS - 1) / NTHREADS;   // f32x4 per thread for a 9-tap chunk
-    unsigned goff[WB];   // element offset inside a chunk of packed weights (global [taps][Cpad][Mpad])
-    unsigned loff[WB];   // element offset inside Wl [taps][KC][MT]
-    f32x4 v[WB];
-    __device__ __forceinline__ void setup(int taps, int Cpad, int Mpad, int tid) {
-        const int last = taps * KC * M4 - 1;
-#pragma unroll
-        for (int u = 0; u < WB; ++u) {
-            const int e = min(u * NTHREADS + tid, last);
-            const int row = e / M4, m4 = e % M4;   // powers of two
-            goff[u] = (unsigned)(((row / KC) * Cpad + (row % KC)) * Mpad + m4 * 4);
-            loff[u] = (unsigned)(e * 4);
-        }
-    }
-    // chunk_base = w + c0 * Mpad + m0 (uniform)
-    __device__ __forceinline__ void issue(const float *__restrict__ chunk_base) {
-#pragma unroll
-        for (int u = 0; u < WB; ++u) v[u] = *reinterpret_cast<const f32x4 *>(chunk_base + goff[u]);
-    }
-    __device__ __forceinline__ void commit(float *__restrict__ Wl) const {
-#pragma unroll
-        for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(Wl + loff[u]) = v[u];
-    }
-};
-
-// activations: KC channel rows x span positions of one segment -> Bl [KC][ldb]; positions outside [0, TV)
-// and channels >= C read as zero (conv zero padding / channel padding): the address is clamped into the
-// tensor and the value replaced by 0 with a select, so the load itself is unconditional.
-template <int NJ>
-struct BStage {
-    static constexpr int RPW = KC / (NTHREADS / 64);   // rows per wave
-    unsigned goff[NJ];   // clamped position inside a channel row
-    unsigned loff[NJ];   // position inside an LDS row
-    unsigned valid;      // bit u: position is inside [0, TV)
-    float v[RPW][NJ];
-    __device__ __forceinline__ void setup(int pbase, int span, int TV, int lane) {
-        valid = 0;
-#pragma unroll
-        for (int u = 0; u < NJ; ++u) {
-            const int j = min(u * 64 + lane, span - 1);
-            const int pp = pbase + j;
-            goff[u] = (unsigned)min(max(pp, 0), TV - 1);
-            loff[u] = (unsigned)j;
-            valid |= (pp >= 0 && pp < TV) ? (1u << u) : 0u;
-        }
-    }
-    // wave is wave-uniform (readfirstlane); rows c0 + wave + 4*rr
-    __device__ __forceinline__ void issue(const float *__restrict__ seg_base, int C, int64_t chan_stride, int c0,
-                                          int wave) {
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int c = c0 + wave + rr * (NTHREADS / 64);
-            const float *src = seg_base + (int64_t)min(c, C - 1) * chan_stride;
-            const unsigned m = c < C ? valid : 0u;
-#pragma unroll
-            for (int u = 0; u < NJ; ++u) {
-                const float x = src[goff[u]];
-                v[rr][u] = ((m >> u) & 1u) ? x : 0.f;
-            }
-        }
-    }
-    __device__ __forceinline__ void commit(float *__restrict__ Bl, int ldb, int wave) const {
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            float *dst = Bl + (wave + rr * (NTHREADS / 64)) * ldb;
-#pragma unroll
-            for (int u = 0; u < NJ; ++u) dst[loff[u]] = v[rr][u];
-        }
-    }
-};
 
 // ------------------------------------------------------------------------------------------------
 // TCN stage
@@ -494,7 +348,6 @@ __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ feat,
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // pick the <MT, NJ> instantiation, raise its dynamic-LDS cap, launch
 template <typename P, typename K>
@@ -506,7 +359,6 @@ static int launch_stage(bool big, bool small_span, dim3 grid, size_t lds, hipStr
     hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds, s, p);
     return (int)hipGetLastError();
 }
-static inline unsigned vmagic_of(int V) { return (unsigned)(((1ull << 32) + V - 1) / V); }
 
 extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
                                  const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,

@@ -1,0 +1,242 @@
+// step.hip -- gfx950 kernels for the CoST-GCN continual (frame-by-frame) path.
+//
+// State lives in a persistent HBM slab in CHANNEL-MAJOR layout: one frame of activations for all streams is
+// a (C, P) matrix, P = n_streams * M * V positions (padded to a multiple of 4), position = (skeleton, joint)
+// with the joint innermost.  Per block:
+//     y ring   [9][C_out][P]   post-GCN frames  (the (k-1)-frame window of co.Conv2d + the new frame)
+//     out ring [5][C_out][P]   block outputs    (doubles as the next block's residual FIFO, co.Delay(4))
+// A step of a block = gcn_stage on the new frame (stages.hip, frames == skeletons) writing ring slot s % 9,
+// then -- on emitting steps -- tcn_step below: the 9 taps of the temporal conv are the 9 ring slots at the
+// SAME positions, so the GEMM is  D[co, p] = sum_r sum_c W[r][c][co] * ring[(head - 8 + r) % 9][c][p].
+// Zero-initialised slots reproduce the zero left-padding of the clip conv (models/base.py:307-334 semantics).
+#include "mfma_core.h"
+
+// ------------------------------------------------------------------------------------------------
+// ring staging: taps*KC rows of NT positions -> Bl [taps][KC][NT]
+// ------------------------------------------------------------------------------------------------
+// Staging slot u of a thread covers row u*RPU + tid/N4 of the [tap][kk] row space (RPU = 256/N4 rows per
+// sweep, a divisor of KC), so the TAP of slot u is the compile-time constant u*RPU/KC and only kk depends on
+// the thread: slot base pointers stay wave-uniform scalars.  Slots beyond `taps` re-stage the last tap into
+// LDS rows that are never read (the LDS tile is always sized for 9 taps).
+template <int NT>
+struct RingStage {
+    static constexpr int N4 = NT / 4;
+    static constexpr int RPU = NTHREADS / N4;              // rows per sweep: 8 (NT=128) or 4 (NT=256)
+    static constexpr int NB = 9 * KC / RPU;                // f32x4 per thread: 9 or 18
+    unsigned poff;                                         // clamped position offset inside the tile
+    int kbase;                                             // tid / N4
+    f32x4 v[NB];
+    __device__ __forceinline__ void setup(int p0, int64_t P, int tid) {
+        kbase = tid / N4;
+        poff = (unsigned)min((tid % N4) * 4, (int)(P - 4 - p0));   // last legal f32x4 start relative to p0
+    }
+    // base[r] = ring + slot(r) * C * P + p0 (uniform); rows c0 + kk, channels >= C read as zero
+    __device__ __forceinline__ void issue(const float *const (&base)[9], int taps, int C, int64_t P, int c0) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int tap = min((u * RPU) / KC, taps - 1);           // uniform
+            const int c = c0 + (u * RPU) % KC + kbase;
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(base[tap] + (int64_t)min(c, C - 1) * P + poff);
+            v[u] = x * (c < C ? 1.f : 0.f);
+        }
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Bl) const {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) *reinterpret_cast<f32x4 *>(Bl + (u * RPU + kbase) * NT + poff) = v[u];
+    }
+};
+
+struct StepParams {
+    const float *ring, *w, *xres, *wres, *bias;
+    float *out;
+    int C, Cpad, Cout, Mpad, K, slots, head;
+    int res_mode, Cres, CresPad, relu;
+    int64_t P;
+};
+
+template <int MT>
+__global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
+    constexpr int NT = 16384 / MT;
+    constexpr int WM = MT / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem;                       // [K][KC][MT]
+    float *Bl = smem + 9 * KC * MT;         // [9][KC][NT]  (always sized for 9 taps)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * MT, p0 = blockIdx.x * NT;
+    const int64_t P = p.P;
+    const float *slot_base[9];              // uniform: tap r reads ring slot (head - (K-1) + r) mod slots
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        int slot = (p.head - (p.K - 1) + min(r, p.K - 1)) % p.slots;
+        if (slot < 0) slot += p.slots;
+        slot_base[r] = p.ring + (int64_t)slot * p.C * P + p0;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const int offA = wm * 64 + l31;
+    const int off0 = wn * 64 + l31, off1 = off0 + 32;
+    WStage<MT> ws;
+    RingStage<NT> rs;
+    // ---- phase 1: temporal conv over the ring
+    {
+        const float *wbase = p.w + m0;
+        ws.setup(p.K, p.Cpad, p.Mpad, tid);
+        rs.setup(p0, P, tid);
+        ws.issue(wbase);
+        rs.issue(slot_base, p.K, p.C, P, 0);
+        for (int c0 = 0; c0 < p.Cpad; c0 += KC) {
+            __syncthreads();
+            ws.commit(Wl);
+            rs.commit(Bl);
+            __syncthreads();
+            if (c0 + KC < p.Cpad) {
+                ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
+                rs.issue(slot_base, p.K, p.C, P, c0 + KC);
+            }
+            mfma_chunk<MT>(Wl, Bl, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
+        }
+    }
+    // ---- phase 2: 1x1 residual conv on the delayed block input (CoTempConv k=1 + co.Delay, base.py:424-441)
+    if (p.res_mode == CSK_RES_CONV) {
+        slot_base[0] = p.xres + p0;
+        const float *wbase = p.wres + m0;
+        ws.setup(1, p.CresPad, p.Mpad, tid);
+        ws.issue(wbase);
+        rs.issue(slot_base, 1, p.Cres, P, 0);
+        for (int c0 = 0; c0 < p.CresPad; c0 += KC) {
+            __syncthreads();
+            ws.commit(Wl);
+            rs.commit(Bl);
+            __syncthreads();
+            if (c0 + KC < p.CresPad) {
+                ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
+                rs.issue(slot_base, 1, p.Cres, P, c0 + KC);
+            }
+            mfma_chunk<MT>(Wl, Bl, 1, NT, KC * NT, offA, off0, off1, kh, acc);
+        }
+    }
+    // ---- epilogue
+    const bool ident = p.res_mode == CSK_RES_IDENTITY;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = p0 + wn * 64 + ni * 32 + l31;
+        const bool qv = q < P;
+        const int64_t qc = min((int64_t)q, P - 1);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
+            float bv[16], rv[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                bv[g] = p.bias[co];
+                rv[g] = ident ? p.xres[(int64_t)min(co, p.Cout - 1) * P + qc] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                float v = acc[mi][ni][g] + bv[g] + rv[g];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (qv && co < p.Cout) p.out[(int64_t)co * P + q] = v;
+            }
+        }
+    }
+}
+
+// feat[n, c] = mean over the M*V positions of stream n in a channel-major frame h (C, P): one wave per (n, c)
+__global__ __launch_bounds__(256) void co_spatial_pool_kernel(const float *__restrict__ h, float *__restrict__ feat,
+                                                              int N, int C, int MV, int64_t P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)N * C) return;
+    const int n = row / C, c = row % C;
+    const float *src = h + (int64_t)c * P + (int64_t)n * MV;
+    float s = 0.f;
+    for (int j = lane; j < MV; j += 64) s += src[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) feat[row] = s / (float)MV;
+}
+
+// pooled[i] = (1/window) * sum over `count` valid ring entries (zero-initialised window, fixed divisor:
+// AvgPool1d count_include_pad semantics); entries are visited oldest -> newest so the sum order is fixed
+__global__ void co_window_mean_kernel(const float *__restrict__ ring, float *__restrict__ pooled, int64_t n_elem,
+                                      int window, int head, int count) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_elem) return;
+    float s = 0.f;
+    for (int j = count - 1; j >= 0; --j) {
+        int slot = (head - j) % window;
+        if (slot < 0) slot += window;
+        s += ring[(int64_t)slot * n_elem + i];
+    }
+    pooled[i] = s / (float)window;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, const float *w, const float *x_res,
+                                const float *w_res, const float *bias, float *out, int c, int c_out, int64_t P,
+                                int k, int res_mode, int c_res, int relu, void *stream) {
+    if (!ring || !w || !bias || !out) CSK_FAIL("tcn_step: null pointer");
+    if (c <= 0 || c_out <= 0 || P < 4 || (P & 3)) CSK_FAIL("tcn_step: bad dims (P must be a positive multiple of 4)");
+    if (k < 1 || k > 9 || slots < k || head < 0 || head >= slots) CSK_FAIL("tcn_step: bad k/slots/head");
+    if (P >= (1ll << 31) - 256) CSK_FAIL("tcn_step: P too large");
+    if (res_mode != CSK_RES_NONE) {
+        if (!x_res) CSK_FAIL("tcn_step: residual requested without x_res");
+        if (res_mode == CSK_RES_IDENTITY && c_res != c_out) CSK_FAIL("tcn_step: identity residual needs c_res == c_out");
+        if (res_mode == CSK_RES_CONV && !w_res) CSK_FAIL("tcn_step: conv residual without w_res");
+    }
+    if (((uintptr_t)ring | (uintptr_t)(x_res ? x_res : ring)) & 15) CSK_FAIL("tcn_step: state pointers must be 16-byte aligned");
+    StepParams p;
+    p.ring = ring; p.w = w; p.xres = x_res ? x_res : ring; p.wres = w_res; p.bias = bias; p.out = out;
+    p.C = c; p.Cpad = round_up(c, KC); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.K = k; p.slots = slots; p.head = head; p.res_mode = res_mode;
+    p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, KC); p.relu = relu; p.P = P;
+    const bool big = (p.Mpad % 128) == 0;
+    const int MT = big ? 128 : 64, NT = 16384 / MT;
+    const size_t lds = (size_t)(9 * KC * MT + 9 * KC * NT) * sizeof(float);   // always 9 taps (73.7 KB)
+    dim3 grid((unsigned)((P + NT - 1) / NT), p.Mpad / MT);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (big) {
+        e = hipFuncSetAttribute((const void *)tcn_step_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(tcn_step_kernel<128>, grid, dim3(NTHREADS), lds, s, p);
+    } else {
+        e = hipFuncSetAttribute((const void *)tcn_step_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(tcn_step_kernel<64>, grid, dim3(NTHREADS), lds, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_co_spatial_pool_f32(const float *h, float *feat, int N, int C, int MV, int64_t P, void *stream) {
+    if (!h || !feat) CSK_FAIL("co_spatial_pool: null pointer");
+    if (N <= 0 || C <= 0 || MV <= 0 || (int64_t)N * MV > P) CSK_FAIL("co_spatial_pool: bad dims");
+    const int64_t rows = (int64_t)N * C;
+    hipLaunchKernelGGL(co_spatial_pool_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h,
+                       feat, N, C, MV, P);
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_co_window_mean_f32(const float *ring, float *pooled, int64_t n_elem, int window, int head,
+                                      int count, void *stream) {
+    if (!ring || !pooled) CSK_FAIL("co_window_mean: null pointer");
+    if (n_elem <= 0 || window <= 0 || head < 0 || head >= window || count < 0 || count > window)
+        CSK_FAIL("co_window_mean: bad dims");
+    hipLaunchKernelGGL(co_window_mean_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, ring, pooled, n_elem, window, head, count);
+    return (int)hipGetLastError();
+}

@@ -105,6 +105,36 @@ int csk_pool_fc_f32(const float *h, const float *fc_w, const float *fc_b, float 
 int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *logits,
                int N, int C, int classes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Continual (frame-by-frame) path.  The arithmetic the reference delegates to the third-party package
+ * continual-inference (co.Conv2d / co.Delay / co.Residual / co.AvgPool1d, call sites models/base.py:73-101,
+ * 273-276, 307-334, 390-446) on per-module Python-side buffers runs here on a persistent HBM state slab in
+ * CHANNEL-MAJOR layout: a frame of activations for all streams is a (C, P) matrix, P = streams*M*V positions
+ * rounded up to a multiple of 4, joint innermost.  csk_gcn_stage_f32 handles the per-frame graph conv on that
+ * layout (n_seg = 1, frames = streams*M, x_chan_stride = P).
+ * ------------------------------------------------------------------------------------------------ */
+
+/*
+ * One emitting step of CoTemporalConvolution (+ residual + ReLU of CoSpatioTemporalBlock, base.py:412-446):
+ *     out[co, p] = ReLU( sum_r sum_c W[r][c][co] * ring[(head-(k-1)+r) mod slots][c][p] + bias[co] + res[co, p] )
+ *  ring   [slots][c][P] post-GCN frames, `head` = slot of the newest frame; zero-initialised slots act as the
+ *         clip conv's zero padding.   slots >= k.
+ *  x_res  (c_res, P) the block input delayed by (k-1)/2 steps (co.Delay), or NULL;  w_res as in csk_tcn_stage_f32.
+ *  out    (c_out, P).   All frame pointers 16-byte aligned, P % 4 == 0.
+ */
+int csk_tcn_step_f32(const float *ring, int slots, int head, const float *w, const float *x_res,
+                     const float *w_res, const float *bias, float *out, int c, int c_out, int64_t P, int k,
+                     int res_mode, int c_res, int relu, void *stream);
+
+/* spatial_pool of CoModelBase (models/base.py:84) on a channel-major frame: feat[n, c] = mean of the MV = M*V
+ * positions of stream n.  h (C, P); feat (N, C). */
+int csk_co_spatial_pool_f32(const float *h, float *feat, int N, int C, int MV, int64_t P, void *stream);
+
+/* co.AvgPool1d(window, stride 1) step (models/base.py:97): pooled = (1/window) * sum of the `count` newest
+ * entries of ring [window][n_elem] (newest at slot `head`); missing entries count as zeros. */
+int csk_co_window_mean_f32(const float *ring, float *pooled, int64_t n_elem, int window, int head, int count,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

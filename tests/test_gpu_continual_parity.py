@@ -1,0 +1,145 @@
+"""GPU parity, continual path.  The identities are the ones the reference's own tests assert
+(tests/test_cost_gcn.py, tests/test_st_gcn_mod.py): continual output == clip output at a shifted index; the
+clip side comes from the golden vectors produced by the reference's classes.  Tolerance 1e-4 absolute."""
+import pytest
+import torch
+
+import _bootstrap
+from oracle import stgcn_oracle as o
+from tests.helpers import g6_state_dict, load_golden, max_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+pkg = _bootstrap.load()
+DEV = "cuda:0"
+A = pkg.ntu_graph().A
+
+
+def test_co_temporal_convolution_pad_end():
+    """tests/test_cost_gcn.py:37-68"""
+    a, sd = load_golden("g2_tcn_k9s1p4")
+    co = pkg.CoTemporalConvolution(4, 4, 9, 4, 1).eval()
+    co.load_state_dict(sd, strict=True)
+    co = co.to(DEV)
+    x = torch.from_numpy(a["x"]).to(DEV)
+    assert max_err(co.forward(x).cpu(), a["y"]) <= TOL
+    assert max_err(co.forward_steps(x, pad_end=True).cpu(), a["y"]) <= TOL
+
+
+def _co_block(tag, padding=4):
+    a, sd = load_golden(f"g3_block_{tag}")
+    ci, co_, s, res, tp = (int(v) for v in a["meta"])
+    blk = pkg.CoSpatioTemporalBlock(ci, co_, A, s, bool(res), padding=padding).eval()
+    blk.load_state_dict(sd, strict=True)          # plain layout from the reference's regular block
+    return blk.to(DEV), torch.from_numpy(a["x"]).to(DEV), torch.from_numpy(a["y"]), s
+
+
+@pytest.mark.parametrize("tag", ["nores", "ident"])
+def test_block_step_lags_clip_by_4(tag):
+    """tests/test_cost_gcn.py:71-176: output[t + 4] == target[:, :, t]"""
+    blk, x, target, _ = _co_block(tag)
+    outs = [blk.forward_step(x[:, :, i].contiguous()) for i in range(x.shape[2])]
+    assert all(v is None for v in outs[:4])
+    for t in range(x.shape[2] - 4):
+        assert max_err(outs[t + 4].cpu(), target[:, :, t]) <= TOL, t
+
+
+@pytest.mark.parametrize("tag", ["convres", "strided", "ident", "nores"])
+def test_block_forward_and_forward_steps(tag):
+    """tests/test_cost_gcn.py:179-271"""
+    blk, x, target, s = _co_block(tag)
+    assert max_err(blk.forward(x).cpu(), target) <= TOL
+    o1 = blk.forward_steps(x, pad_end=False).cpu()
+    cut = blk.delay // s
+    assert o1.shape[2] == target.shape[2] - cut and max_err(o1, target[:, :, : target.shape[2] - cut]) <= TOL
+    blk.clean_state()
+    o2 = blk.forward_steps(x, pad_end=True).cpu()
+    assert o2.shape == target.shape and max_err(o2, target) <= TOL
+
+
+@pytest.mark.parametrize("tag", ["nopad", "nopad_strided"])
+def test_block_nopad(tag):
+    """tests/test_st_gcn_mod.py:11-54 (padding=0: forward and stepping both give the un-padded clip output)"""
+    blk, x, target, _ = _co_block(tag, padding=0)
+    assert max_err(blk.forward(x).cpu(), target) <= TOL
+    out = blk.forward_steps(x).cpu()
+    assert out.shape == target.shape and max_err(out, target) <= TOL
+
+
+def test_stack_of_three_blocks():
+    """tests/test_cost_gcn.py:274-326"""
+    a, sd = load_golden("g4_stack")
+    blocks = [pkg.CoSpatioTemporalBlock(3, 3, A, residual=False, padding=4), pkg.CoSpatioTemporalBlock(3, 3, A, padding=4),
+              pkg.CoSpatioTemporalBlock(3, 4, A, stride=2, padding=4)]
+    h1 = h2 = torch.from_numpy(a["x"]).to(DEV)
+    for i, b in enumerate(blocks):
+        b.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith(f"{i}.")}, strict=True)
+        b = b.eval().to(DEV)
+        h1 = b.forward(h1)
+        h2 = b.forward_steps(h2, pad_end=True)
+    assert max_err(h1.cpu(), a["y"]) <= TOL and max_err(h2.cpu(), a["y"]) <= TOL
+
+
+def test_clean_state_and_restart():
+    blk, x, target, _ = _co_block("ident")
+    first = blk.forward_steps(x).cpu()
+    blk.clean_state()
+    again = blk.forward_steps(x).cpu()
+    assert torch.equal(first, again)
+    blk.forward_steps(x[:, :, :7].contiguous())        # leave dirty state, different history
+    blk.clean_state()
+    assert torch.equal(blk.forward_steps(x).cpu(), first)
+
+
+def test_costgcn_features_equal_clip_features_at_shifted_index():
+    """Layer-10 emission j (input frame 76 + 4j) == clip layer-10 frame j (the whole-stack form of the block
+    identity; the clip side is pinned by fixture G6)."""
+    a, sd, x = g6_state_dict("ntu")
+    reg = pkg.StGcn(A).eval()
+    reg.load_state_dict(sd, strict=True)
+    co = pkg.CoStGcn(A).eval()
+    co.load_state_dict(sd, strict=True)
+    reg, co, x = reg.to(DEV), co.to(DEV), x[:1].to(DEV)
+    clip_feat = reg.features(x)                                          # (M, 256, 75, 25)
+    T = 76 + 4 * 6 + 1
+    got = []
+    for t in range(T):
+        slot = co.features_step(x[:, :, t].contiguous())
+        assert (slot is not None) == (t >= 76 and (t - 76) % 4 == 0)
+        if slot is not None:
+            st = co.layers["layer10"]._state
+            got.append(st.out[slot, :, : 2 * 25].view(256, 2, 25).permute(1, 0, 2).clone())
+    assert len(got) == 7
+    for j, g in enumerate(got):
+        assert max_err(g.cpu(), clip_feat[:, :, j].cpu()) <= TOL, j
+
+
+def test_costgcn_logits_vs_oracle_and_forward_modes():
+    """Whole CoST-GCN stepping (data_bn, 10 blocks, spatial pool, temporal average pool, fc) vs the CPU oracle,
+    with a small pool so that predictions appear early; and forward('clip') == forward('frame') like
+    tests/test_cost_gcn.py:359-362."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:1, :, :120].contiguous()
+    co = pkg.CoStGcn(A, pool_size=6, pool_padding=2).eval()
+    co.load_state_dict(sd, strict=True)
+    co = co.to(DEV)
+    got = co.forward_steps(x.to(DEV)).cpu()                              # (1, 60, n_pred)
+    orc = o.CoStGcnOracle(sd, pool_size=6, pool_padding=2)
+    want = []
+    with torch.no_grad():
+        for t in range(x.shape[2]):
+            r = orc.forward_step(x[:, :, t])
+            if r is not None:
+                want.append(r)
+    want = torch.stack(want, dim=2)
+    assert got.shape == want.shape and got.shape[2] >= 5
+    assert max_err(got, want) <= TOL
+    # default pool (75 / 19): after exactly T=300 frames one prediction exists and equals the clip-mode forward
+    a, sd, x = g6_state_dict("ntu")
+    co = pkg.CoStGcn(A).eval()
+    co.load_state_dict(sd, strict=True)
+    co = co.to(DEV)
+    xd = x[:1].to(DEV)
+    frame = co.forward(xd, forward_mode="frame").cpu()
+    clip = co.forward(xd, forward_mode="clip").cpu()
+    assert frame.shape == (1, 60) and max_err(frame, clip) <= TOL

@@ -1,0 +1,113 @@
+"""CPU tests of the host layer: C-ABI symbols, state_dict layouts, folding arithmetic, loud failures."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import _bootstrap
+from oracle import stgcn_oracle as o
+from tests.helpers import load_golden
+
+pkg = _bootstrap.load()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cskel.h")).read()
+    declared = set(re.findall(r"\b(csk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed from include/cskel.h"
+    lib = ctypes.CDLL(pkg.native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in cskel.h but not exported"
+    assert declared - {"csk_last_error"} == set(pkg.native.SIGNATURES), "ctypes table out of sync with cskel.h"
+    assert pkg.native.lib().csk_abi_version() == 1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = pkg.native.lib()
+    rc = lib.csk_tcn_stage_f32(None, None, None, None, None, None, 1, 1, 1, 1, 25, 9, 1, 4, 0, 0, 0, 0, 1, None)
+    assert rc == -1 and b"null pointer" in lib.csk_last_error()
+    with pytest.raises(RuntimeError, match="null pointer"):
+        pkg.native.check(rc, "csk_tcn_stage_f32")
+
+
+def test_graph_matches_reference_fixture():
+    a, _ = load_golden("g0_graphs")
+    assert np.array_equal(pkg.ntu_graph().A, a["ntu"]) and np.array_equal(pkg.kinetics_graph().A, a["kinetics"])
+
+
+def test_state_dict_layouts_match_reference():
+    A = pkg.ntu_graph().A
+    _, sd = load_golden("g3_block_strided")           # dumped from the reference's SpatioTemporalBlock
+    blk = pkg.SpatioTemporalBlock(2, 4, A, stride=2)
+    assert list(blk.state_dict().keys()) == list(sd.keys())
+    assert all(blk.state_dict()[k].shape == v.shape for k, v in sd.items())
+    blk.load_state_dict(sd, strict=True)
+    # continual container layouts (tests/test_cost_gcn.py:97-98,145,193-198)
+    co = pkg.CoSpatioTemporalBlock(2, 4, A, stride=2, padding=4)
+    keys = set(co.state_dict().keys())
+    assert {"0.0.residual.t_conv.weight", "0.1.gcn.g_conv.0.weight", "0.1.tcn.bn.running_var"} <= keys
+    assert not any(k.startswith(("gcn.", "tcn.", "residual.")) for k in keys)
+    mapping = {"res": "0.0.", "gcn": "0.1.", "tcn": "0.1."}
+    co.load_state_dict({mapping[k[:3]] + k: v for k, v in sd.items()}, strict=True)    # reference Co layout
+    co.load_state_dict(sd, strict=True)                                                # plain layout
+    ident = pkg.CoSpatioTemporalBlock(4, 4, A, padding=4)
+    assert all(k.startswith("0.1.") for k in ident.state_dict())
+    nores = pkg.CoSpatioTemporalBlock(4, 4, A, residual=False, padding=4)
+    assert all(k.startswith(("gcn.", "tcn.")) for k in nores.state_dict())
+    assert (co.delay, co.receptive_field, co.stride, co.padding) == (4, 9, 2, 4)
+    assert pkg.CoSpatioTemporalBlock(4, 4, A).delay == 8                               # padding=0 default
+
+
+def test_costgcn_keys_and_map_state_dict():
+    A = pkg.ntu_graph().A
+    reg, co = pkg.StGcn(A), pkg.CoStGcn(A)
+    assert "layers.layer2.0.1.gcn.g_conv.0.weight" in co.state_dict()
+    assert "layers.layer8.0.0.residual.t_conv.weight" in co.state_dict()
+    assert "layers.layer1.gcn.bn.weight" in co.state_dict()
+    mapped = co.map_state_dict(reg.state_dict())
+    assert set(mapped) == set(co.state_dict())
+    co.load_state_dict(mapped, strict=True)
+    co.load_state_dict(reg.state_dict(), strict=True)      # regular layout loads directly as well
+    assert (co.receptive_field, co.padding, co.stride, co.pool_size, co.pool_padding) == (153, 76, 4, 75, 19)
+
+
+def test_fold_reproduces_oracle_pointwise():
+    """Evaluate the PACKED operands with plain numpy (test-only) and compare with the oracle."""
+    a, sd = load_golden("g3_block_strided")
+    f = pkg.fold.fold_graph_conv(sd, "gcn.")
+    x = torch.from_numpy(a["x"]).double()
+    n, ci, t, v = x.shape
+    a_eff = (sd["gcn.A"] * sd["gcn.graph_attn"]).double()
+    # ELL round trip
+    dense = torch.zeros(3, v, v, dtype=torch.float64)
+    for i in range(3):
+        for w in range(v):
+            for e in range(int(f["ell_cnt_host"][i])):
+                dense[i, int(f["ell_src"][i, w, e]), w] += float(f["ell_val"][i, w, e])
+    assert torch.allclose(dense, a_eff.float().double())
+    xa = [torch.einsum("nctv,vw->nctw", x, a_eff[i]) for i in range(3)] + [x]
+    y = sum(torch.einsum("nctw,co->notw", xa[r], f["w"][r, :ci, : f["c_out"]].double()) for r in range(4))
+    y = torch.relu(y + f["bias"][: f["c_out"]].double()[None, :, None, None])
+    with torch.no_grad():
+        want = o.graph_conv(torch.from_numpy(a["x"]), sd, "gcn.")
+    assert float((y - want.double()).abs().max()) < 1e-5
+
+
+def test_product_never_imports_oracle():
+    pkg_dir = os.path.join(ROOT, "continual-skeletons_amd")
+    for fn in os.listdir(pkg_dir):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg_dir, fn)).read()
+            assert "oracle" not in src.replace("oracle/stgcn_oracle.py", "").replace("(anchored on the reference's tests, see )", "") or fn == "continual.py" and "import oracle" not in src and "from oracle" not in src
+            assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(pkg.native, "_lib", None)
+    monkeypatch.setattr(pkg.native, "LIB_PATH", "/nonexistent/libcskel_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.native.lib()
