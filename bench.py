@@ -110,6 +110,88 @@ def cpu_baseline_clip(seed, threads):
                 sample=f"{n} passes of 8 NTU-60 clips (batch 8) through oracle.stgcn_forward, torch CPU fp32")
 
 
+def step_flops_per_cycle(nm, c_in=3, V=25):
+    """Algorithmic FLOPs of one 4-frame stride cycle of the ten continual blocks for nm skeletons (SURVEY 8d:
+    28.75 MMAC per skeleton-frame, frame-rate weighted): (gcn_flops, tcn_flops)."""
+    from oracle.stgcn_oracle import layer_table
+    rate, g, t = 4, 0, 0            # frames per 4-frame cycle entering the block
+    for (ci, co, s, res) in layer_table(c_in):
+        r = 4 if ci != co else 3
+        g += rate * r * ci * co * V
+        rate //= s
+        t += rate * (9 * co * co + (ci * co if (res and (ci != co or s != 1)) else 0)) * V
+    return 2 * g * nm, 2 * t * nm
+
+
+def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist):
+    """CoST-GCN online inference: `streams` concurrent streams per GPU, persistent ring-buffer state; one
+    cycle = 4 consecutive frames (the stack's stride pattern) = one prediction per stream."""
+    net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+    randomise_(net, seed=0)
+    net = net.to(dev)
+    g = torch.Generator(device=dev).manual_seed(200 + rank)
+    frames = torch.rand((8, streams, NTU["C"], NTU["V"], NTU["M"]), device=dev, generator=g)   # resident inputs
+    net.warm_up(streams, dev)                               # 76 frames (models/base.py:144-159)
+    for _ in range(75 - 19 - 1):                            # fill the temporal pool so every cycle predicts
+        for f in range(4):
+            net.forward_step(frames[f])
+    fi = 0
+
+    def cycle():
+        nonlocal fi
+        out = None
+        for _ in range(4):
+            o = net.forward_step(frames[fi % 8])
+            fi += 1
+            out = o if o is not None else out
+        return parallel.all_gather_logits(out) if world > 1 else out
+
+    timers = [LaunchTimer(pkg, "tcn_step_launch")]
+    with timers[0] as lt:
+        for _ in range(warm_cycles):
+            out = cycle()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lt.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            out = cycle()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lt.enabled = False
+        tcn_ms, n_launch = lt.total_ms(), len(lt.records)
+    assert out is not None and out.shape == (streams * world, NTU["classes"]) and bool(torch.isfinite(out).all())
+    return dt, tcn_ms, n_launch, net.state_bytes()
+
+
+def cpu_baseline_step(seed):
+    """Oracle continual path (port of the reference op sequence + restated continual protocol), one stream."""
+    from oracle import stgcn_oracle as o
+    import _bootstrap
+    pkg = _bootstrap.load()
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(threads)
+    net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+    randomise_(net, seed)
+    sd = {k: v.clone() for k, v in pkg.StGcn(pkg.ntu_graph().A).state_dict().items()}
+    sd.update({k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in net.state_dict().items()})
+    orc = o.CoStGcnOracle(sd)
+    x = torch.rand((1, NTU["C"], 200, NTU["V"], NTU["M"]), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        for t in range(76):
+            orc.forward_step(x[:, :, t])
+        t0, n = time.perf_counter(), 0
+        while n < 120 and (time.perf_counter() - t0) < 20.0:
+            orc.forward_step(x[:, :, 76 + n])
+            n += 1
+        dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 2), unit="frames/s", cores=threads, kind="port",
+                sample=f"{n} steady-state frames of one NTU-60 stream after 76 warm-up frames, oracle.CoStGcnOracle")
+
+
 def load_traffic():
     """Per-launch HBM bytes of the dominant kernel from the committed PMC summary (profiles/), or None."""
     p = os.path.join(ROOT, "profiles", "traffic_tcn_stage.json")
@@ -124,8 +206,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="clip", choices=["clip"])
+    ap.add_argument("--workload", default="both", choices=["both", "clip", "step"],
+                    help="'both' (default): primary metric = clip, CoST-GCN online step reported in the same line")
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--streams", type=int, default=1024, help="concurrent CoST-GCN streams per GPU")
+    ap.add_argument("--step-cycles", type=int, default=16, help="timed 4-frame cycles of the online workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -147,9 +232,11 @@ def main():
     pkg = _bootstrap.load()
     from continual_skeletons_amd import parallel
 
-    cpu = None
+    cpu = cpu_step = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_clip(seed=0, threads=os.cpu_count() or 1)
+        cpu = cpu_baseline_clip(seed=0, threads=min(len(os.sched_getaffinity(0)), 32))
+        if args.workload in ("both", "step"):
+            cpu_step = cpu_baseline_step(seed=0)
 
     B = args.batch
     net = pkg.StGcn(pkg.ntu_graph().A, input_shape=(NTU["C"], NTU["T"], NTU["V"], NTU["M"]), num_classes=NTU["classes"]).eval()
@@ -186,6 +273,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    step_info = None
+    if args.workload in ("both", "step"):
+        del x, out
+        net = None
+        torch.cuda.empty_cache()
+        sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist)
+        tt = torch.tensor([sdt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sdt = float(tt.item())
+        gfl, tfl = step_flops_per_cycle(args.streams * NTU["M"])
+        fps = 4 * args.streams * world * args.step_cycles / sdt
+        ach = tfl * args.step_cycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0
+        step_info = {"metric": "skeleton frames/sec (CoST-GCN online step, NTU-60 shape)", "value": round(fps, 1),
+                     "unit": "frames/s", "streams_per_gpu": args.streams, "ms_per_frame_step": round(sdt / args.step_cycles / 4 * 1e3, 4),
+                     "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
+                     "roofline": {"bound": "mfma", "kernel": "tcn_step_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,
+                                  "avg_launch_ms": round(stcn_ms / max(1, sn), 4)},
+                     "cpu_baseline": cpu_step, "config": "BASELINE.json configs[2]"}
     if rank == 0:
         clips = B * world * args.steps
         flops_launch = tcn_flops_per_clip_forward(B * NTU["M"]) / 10.0       # average over the 10 launches / step
@@ -209,6 +316,7 @@ def main():
                          "flops_per_launch": flops_launch,
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None},
             "cpu_baseline": cpu,
+            "costgcn_online": step_info,
         }
         print(json.dumps(line))
     if world > 1:

@@ -223,3 +223,8 @@ class SpatioTemporalBlock(_Folded):
             mode, xr = 2, x
         return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
                          res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink)
+
+
+def tcn_step_launch(*args):
+    """csk_tcn_step_f32 launch (module-level so that bench.py can time it with HIP events)."""
+    native.check(native.lib().csk_tcn_step_f32(*args), "csk_tcn_step_f32")

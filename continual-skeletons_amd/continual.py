@@ -24,7 +24,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import fold, native
+from . import blocks, fold, native
 from .blocks import (GraphConvolution, SpatioTemporalBlock, TemporalConvolution, _Folded, gcn_stage,
                      init_weights, unity, zero)
 from .models import layer_table
@@ -219,11 +219,10 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             mode = {"none": 0, "identity": 1, "conv": 2}[self.kind]
             xres = st.xin[(s - lag) % HIST] if mode else None
             slot = st.e % HIST
-            rc = native.lib().csk_tcn_step_f32(
+            blocks.tcn_step_launch(
                 native.ptr(st.y), k, s % k, native.ptr(ops["w"]), native.ptr(xres), native.ptr(ops["w_res"]),
                 native.ptr(ops["bias"]), native.ptr(st.out[slot]), self.out_channels, self.out_channels, st.p, k,
                 mode, self.in_channels if mode else 0, 1, native.stream_of(st.y))
-            native.check(rc, "csk_tcn_step_f32")
             st.e += 1
         st.s += 1
         return slot
