@@ -31,6 +31,15 @@ __device__ __forceinline__ int div_magic(int x, unsigned magic) {
     return (int)__umulhi((unsigned)x, magic);
 }
 
+// XCD-aware work-item id: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so a
+// linear blockIdx puts neighbouring tiles -- which share temporal halos and weight panels -- on eight
+// different L2s.  Remap so that every XCD walks a CONTIGUOUS range of work items (bijective for any grid
+// size; placement is a speed assumption only, never a correctness one).
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned total) {
+    const unsigned q = total / 8, r = total % 8, xcd = bid % 8, k = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // One K-chunk of the shifted GEMM for one wave: acc[mi][ni] += W[r][kk][rows] x B[r][kk][cols].
 //   Wl : [taps][KC][MT]  (row = output channel contiguous -> A operand, lane i = l&31, k = l>>5)
 //   Bl : B value of (tap r, channel kk, column) at Bl[r*tapB + kk*ldb + off_ni]

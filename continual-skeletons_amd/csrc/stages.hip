@@ -33,7 +33,7 @@ struct TcnParams {
     float *out;
     int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
     int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
-    unsigned vmagic;
+    unsigned vmagic, mtiles, qtiles;
     int debug;   // TEMP ablation bits
 };
 
@@ -48,7 +48,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int seg = blockIdx.y, m0 = blockIdx.z * MT, q0 = blockIdx.x * NT;
+    // work item -> (m-tile fastest: shares the activation tile; then position tile: shares halos; then segment)
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
+    const int seg = (int)(wid / (p.mtiles * p.qtiles));
     const int V = p.V, Q = p.Tout * V;
     const int qend = min(q0 + NT, Q);
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
@@ -171,7 +174,7 @@ struct GcnParams {
     int ell_w;
     int64_t adj_seg_stride, x_seg_stride, x_chan_stride, y_seg_stride, y_chan_stride;
     int Cin, CinPad, Cout, Mpad, frames, V, R, res_mode, ldb;
-    unsigned vmagic;
+    unsigned vmagic, mtiles, qtiles;
 };
 
 template <int MT, int NJ>
@@ -191,7 +194,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int seg = blockIdx.y, m0 = blockIdx.z * MT, q0 = blockIdx.x * NT;
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
+    const int seg = (int)(wid / (p.mtiles * p.qtiles));
     const int Q = p.frames * V;
     const int qend = min(q0 + NT, Q);
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
@@ -295,6 +300,177 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
 }
 
 // ------------------------------------------------------------------------------------------------
+// GCN stage, sparse-graph fast path: the aggregated B operand is formed ON THE FLY in the MFMA loop.
+// For skeleton graphs A_eff has <= 1 / 1 / 4 non-zeros per column in the self / inward / outward subsets
+// (NTU-25: 1/1/4, OpenPose-18: 1/1/3), so every lane keeps the <= 6 (LDS offset, weight) pairs of its two
+// output columns in registers and builds   B_r[c][q] = sum_e val * x[c][frame(q), src_e]   with <= 6 LDS reads
+// + FMAs per k-step, against 12-16 MFMAs (768-1024 cycles) that consume them.  No aggregated tile, no
+// aggregation phase, one barrier pair per 16 channels.  Dense / per-sample adjacencies (A-GCN) use the
+// general kernel above.
+// ------------------------------------------------------------------------------------------------
+static constexpr int KCG = CSK_CPAD;    // channels per barrier pair == the zero-padding granule of the packed weights
+
+template <int MT, bool CONVRES>
+__global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const GcnParams p) {
+    constexpr int NT = 16384 / MT;
+    constexpr int WM = MT / 64;
+    constexpr int R = CONVRES ? 4 : 3;
+    constexpr int M4 = MT / 4;
+    constexpr int WB = R * KCG * M4 / NTHREADS;            // f32x4 of weights per thread per chunk (6 or 8 / 3 or 4)
+    constexpr int RPW = KCG / (NTHREADS / 64);             // activation rows per wave per chunk (4)
+    constexpr int NJ = 5;                                  // 64-lane sweeps per activation row (span <= 320)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int V = p.V;
+    float *Wl = smem;                                      // [R][KCG][MT]
+    float *Bx = smem + R * KCG * MT;                       // [KCG][ldb]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
+    const int seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int Q = p.frames * V;
+    const int qend = min(q0 + NT, Q);
+    const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
+    const int span = (tb - ta + 1) * V;
+
+    // per-lane adjacency entries of the two output columns this lane feeds (B operand: column = lane & 31)
+    int eoff[2][6];
+    float eval[2][6];
+    int ioff[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+        const int t = div_magic(q, p.vmagic);
+        const int w = q - t * V, fb = (t - ta) * V;
+        ioff[ni] = fb + w;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;          // subsets 0,1: one entry; subset 2: four
+            const bool have = k < p.ell_cnt[r];
+            const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
+            eoff[ni][e] = fb + (have ? p.ell_src[idx] : 0);
+            eval[ni][e] = have ? p.ell_val[idx] : 0.f;
+        }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
+    const float *wbase = p.w + m0;
+    // staging registers + chunk-invariant offsets
+    f32x4 wv[WB];
+    unsigned wgo[WB], wlo[WB];
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+        const int e = u * NTHREADS + tid;                  // exact cover: R*KCG*M4 is a multiple of 256
+        const int row = e / M4, m4 = e % M4;
+        wgo[u] = (unsigned)(((row / KCG) * p.CinPad + (row % KCG)) * p.Mpad + m4 * 4);
+        wlo[u] = (unsigned)(e * 4);
+    }
+    float bv[RPW][NJ];
+    unsigned bgo[NJ], blo[NJ];
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+        const int j = min(u * 64 + lane, span - 1);
+        bgo[u] = (unsigned)(ta * V + j);                   // always inside [0, Q): whole frames of this segment
+        blo[u] = (unsigned)j;
+    }
+    auto issue = [&](int c0) {
+        const float *wc = wbase + (size_t)c0 * p.Mpad;
+#pragma unroll
+        for (int u = 0; u < WB; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(wc + wgo[u]);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int c = c0 + wave + rr * (NTHREADS / 64);
+            const float *src = seg_base + (int64_t)min(c, p.Cin - 1) * p.x_chan_stride;
+            const float m = c < p.Cin ? 1.f : 0.f;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) bv[rr][u] = src[bgo[u]] * m;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(Wl + wlo[u]) = wv[u];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            float *dst = Bx + (wave + rr * (NTHREADS / 64)) * p.ldb;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) dst[blo[u]] = bv[rr][u];
+        }
+    };
+
+    const int offA = wm * 64 + l31;
+    const int cpad = p.CinPad;                             // multiple of CSK_CPAD == KCG (zero-padded weights)
+    issue(0);
+    for (int c0 = 0; c0 < cpad; c0 += KCG) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (c0 + KCG < cpad) issue(c0 + KCG);
+#pragma unroll 2
+        for (int s = 0; s < KCG / 2; ++s) {
+            const int kk = 2 * s + kh;
+            const float *bx = Bx + kk * p.ldb;
+            float b[R][2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float x0 = bx[eoff[ni][0]];
+                b[0][ni] = eval[ni][0] * x0;
+                b[1][ni] = eval[ni][1] * bx[eoff[ni][1]];
+                float s2 = eval[ni][2] * bx[eoff[ni][2]];
+                s2 = fmaf(eval[ni][3], bx[eoff[ni][3]], s2);
+                s2 = fmaf(eval[ni][4], bx[eoff[ni][4]], s2);
+                s2 = fmaf(eval[ni][5], bx[eoff[ni][5]], s2);
+                b[2][ni] = s2;
+                if (CONVRES) b[R - 1][ni] = bx[ioff[ni]];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float *wr = Wl + (r * KCG + kk) * MT + offA;
+                const float a0 = wr[0], a1 = wr[32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][1], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+
+    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = q0 + wn * 64 + ni * 32 + l31;
+        const bool qv = q < Q;
+        const int qc = min(q, Q - 1);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
+            float bb[16], rv[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                bb[g] = p.bias[co];
+                rv[g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co = cb + (g & 3) + 8 * (g >> 2);
+                const float v = fmaxf(acc[mi][ni][g] + bb[g] + rv[g], 0.f);
+                if (qv && co < p.Cout) oseg[(int64_t)co * p.y_chan_stride + q] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pre / post
 // ------------------------------------------------------------------------------------------------
 __global__ void input_norm_kernel(const float *__restrict__ x, const float *__restrict__ scale,
@@ -378,9 +554,9 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     if ((int64_t)t_in * V >= (1 << 26)) CSK_FAIL("tcn_stage: T*V too large for 32-bit position arithmetic");
     TcnParams p;
     p.y = y; p.w = w; p.xres = x_res ? x_res : y; p.wres = w_res; p.bias = bias; p.out = out;
-    p.C = c; p.Cpad = round_up(c, KC); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.stride = stride; p.pad = pad;
-    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, KC);
+    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD);
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
     { const char *d = getenv("CSK_DEBUG"); p.debug = d ? atoi(d) : 0; }
     const bool big = (p.Mpad % 128) == 0;
@@ -390,7 +566,9 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     const size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
     if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = t_out * V;
-    dim3 grid((Q + NT - 1) / NT, n_seg, p.Mpad / MT);
+    p.qtiles = (Q + NT - 1) / NT; p.mtiles = p.Mpad / MT;
+    if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage: grid too large");
+    dim3 grid(p.qtiles * p.mtiles * n_seg);
     const int nj = (p.ldb + 63) / 64;
     if (nj > 14) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
     return launch_stage(big, nj <= 9, grid, lds, (hipStream_t)stream, p,
@@ -416,7 +594,7 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     p.ell_w = ell_w; p.adj_seg_stride = adj_seg_stride;
     p.x_seg_stride = x_seg_stride; p.x_chan_stride = x_chan_stride;
     p.y_seg_stride = y_seg_stride; p.y_chan_stride = y_chan_stride;
-    p.Cin = c_in; p.CinPad = round_up(c_in, KC); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.frames = frames; p.V = V; p.R = res_mode == CSK_RES_CONV ? 4 : 3; p.res_mode = res_mode;
     p.vmagic = vmagic_of(V);
     const bool big = (p.Mpad % 128) == 0;
@@ -427,7 +605,22 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     if (lds > 160 * 1024) CSK_FAIL("gcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = frames * V;
     if ((int64_t)frames * V >= (1 << 26)) CSK_FAIL("gcn_stage: frames*V too large for 32-bit position arithmetic");
-    dim3 grid((Q + NT - 1) / NT, n_seg, p.Mpad / MT);
+    p.qtiles = (Q + NT - 1) / NT; p.mtiles = p.Mpad / MT;
+    if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
+    dim3 grid(p.qtiles * p.mtiles * n_seg);
+    // sparse-graph fast path: shared adjacency with <= 1/1/4 non-zeros per column, activation tile <= 320 positions
+    const bool sparse = adj_seg_stride == 0 && ell_cnt[0] <= 1 && ell_cnt[1] <= 1 && ell_cnt[2] <= 4 && p.ldb <= 320 &&
+                        !getenv("CSK_GCN_GENERAL");
+    if (sparse) {
+        const int R = p.R;
+        const size_t lds2 = (size_t)(R * KCG * MT + KCG * p.ldb) * sizeof(float);
+        void (*k)(GcnParams) = big ? (R == 4 ? gcn_stage_sparse_kernel<128, true> : gcn_stage_sparse_kernel<128, false>)
+                                   : (R == 4 ? gcn_stage_sparse_kernel<64, true> : gcn_stage_sparse_kernel<64, false>);
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds2, (hipStream_t)stream, p);
+        return (int)hipGetLastError();
+    }
     const int nj = (p.ldb + 63) / 64;
     if (nj > 14) CSK_FAIL("gcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
     return launch_stage(big, nj <= 9, grid, lds, (hipStream_t)stream, p,

@@ -201,9 +201,9 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, const fl
     if (((uintptr_t)ring | (uintptr_t)(x_res ? x_res : ring)) & 15) CSK_FAIL("tcn_step: state pointers must be 16-byte aligned");
     StepParams p;
     p.ring = ring; p.w = w; p.xres = x_res ? x_res : ring; p.wres = w_res; p.bias = bias; p.out = out;
-    p.C = c; p.Cpad = round_up(c, KC); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.K = k; p.slots = slots; p.head = head; p.res_mode = res_mode;
-    p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, KC); p.relu = relu; p.P = P;
+    p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD); p.relu = relu; p.P = P;
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const size_t lds = (size_t)(9 * KC * MT + 9 * KC * NT) * sizeof(float);   // always 9 taps (73.7 KB)

@@ -10,7 +10,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
-KC = 8    # CSK_KC
+KC = 16   # CSK_CPAD: packed weights zero-pad C_in to a multiple of this
 MT = 64   # CSK_MT
 BN_EPS = 1e-5
 

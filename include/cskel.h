@@ -12,7 +12,7 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous,
  *    no allocation and no synchronisation happens inside any call (graph-capture safe).
  *  - packed weights are produced once on the host by continual-skeletons_amd/fold.py
- *    (BatchNorm(eval) + bias folding, zero padding of channel counts to CSK_KC / CSK_MT multiples).
+ *    (BatchNorm(eval) + bias folding, zero padding of channel counts to CSK_CPAD / CSK_MT multiples).
  *  - return value: 0 = ok; <0 = argument error (see csk_last_error()); >0 = hipError_t of the launch.
  */
 #ifndef CSKEL_H
@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 #define CSK_ABI_VERSION 1
-#define CSK_KC 8   /* channel-chunk of the K loop; packed weights pad C_in to a multiple of this   */
+#define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
+#define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
 
 /* residual forms of SpatioTemporalBlock (models/base.py:367-374) and GraphConvolution (:246-254) */

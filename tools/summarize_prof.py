@@ -61,8 +61,9 @@ def main(tag):
     cal = known / (max(cal_raw) * 1024) if cal_raw else 1.0
     lines += ["", "## HBM traffic per launch (PMC, separate passes, clip workload batch 256)", "",
               f"Read calibration: input_norm_kernel reads {known / 1e6:.2f} MB; raw FETCH_SIZE = {max(cal_raw) if cal_raw else 0:.0f} KiB"
-              f" -> factor {cal:.3f} (MI355X_MICROARCH.md quotes x2 for 16-B-per-lane streams; our activation loads are"
-              " 4 B per lane, for which the counter reads the bytes directly).  Read MB below = raw KiB x 1024 x factor.", "",
+              f" -> factor {cal:.3f} (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2;"
+              " confirmed here on a kernel of known traffic).  Read MB below = raw KiB x 1024 x factor; reads served by the"
+              " Infinity Cache are included (the counter sits on the L2's fabric side).", "",
               "| kernel | launches | FETCH_SIZE raw avg KiB | WRITE_SIZE raw avg KiB | HBM read MB (calibrated) | HBM write MB |", "|---|---|---|---|---|---|"]
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, {}).get("FETCH_SIZE", [])
