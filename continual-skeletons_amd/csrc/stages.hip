@@ -34,7 +34,7 @@ struct TcnParams {
     int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
     int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
     unsigned vmagic, mtiles, qtiles;
-    int debug;   // TEMP ablation bits
+    unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
 
 template <int MT, int NJ>
@@ -73,8 +73,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
     const int offA = wm * 64 + l31;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
     WStage<MT> ws;
     BStage<NJ> bs;
+    // epilogue operands: 32 biases + (identity residual) 64 block-input values per lane.  They are loaded
+    // UNDER THE LAST CHUNK'S MFMAs (the K loops are peeled by one iteration; the staging registers are dead
+    // there), unconditionally (clamped indices, bias padded to Mpad), so the epilogue itself is stores only.
+    float *oseg = p.out + (int64_t)seg * p.Cout * Q;
+    const float *rseg = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+    const int64_t rcs = (int64_t)p.Tres * V;
+    const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    float bv[2][16], rv[2][2][16];
+    auto issue_epilogue_loads = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+            const int t = div_magic(qc, p.vmagic);
+            const int qres = ident ? (t * p.stride + p.res_off) * V + (qc - t * V) : 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int co = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    rv[ni][mi][g] = ident ? rseg[(int64_t)min(co, p.Cout - 1) * rcs + qres] : 0.f;
+                }
+        }
+    };
+    const bool conv_res = p.res_mode == CSK_RES_CONV;
     // ---- phase 1: k x 1 temporal conv over y
     {
         const int fa = p.stride * ta - p.pad;
@@ -86,23 +116,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         bs.setup(fa * V, span, p.Tin * V, lane);
         ws.issue(wbase);
         bs.issue(seg_base, p.C, cs, 0, wave);
-        for (int c0 = 0; c0 < p.Cpad; c0 += KC) {
-            const bool first = c0 == 0;
-            if (first || !(p.debug & 4)) __syncthreads();                       // previous chunk's LDS reads are done
-            if (first || !(p.debug & 1)) {
+        int c0 = 0;
+        for (; c0 + KC < p.Cpad; c0 += KC) {
+            __syncthreads();                       // previous chunk's LDS reads are done
             ws.commit(Wl);
             bs.commit(Bl, p.ldb, wave);
-            }
-            if (first || !(p.debug & 4)) __syncthreads();
-            if (c0 + KC < p.Cpad && !(p.debug & 2)) {                // next chunk's loads fly underneath the MFMAs below
-                ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
-                bs.issue(seg_base, p.C, cs, c0 + KC, wave);
-            }
+            __syncthreads();
+            if (p.stamps && c0 == 0) st1 = __builtin_amdgcn_s_memtime();
+            ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);      // next chunk's loads fly underneath the MFMAs
+            bs.issue(seg_base, p.C, cs, c0 + KC, wave);
             mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
         }
+        __syncthreads();                           // peeled last chunk
+        ws.commit(Wl);
+        bs.commit(Bl, p.ldb, wave);
+        __syncthreads();
+        if (!conv_res) issue_epilogue_loads();
+        mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
     }
     // ---- phase 2: 1x1 strided residual conv over the block input (models/base.py:372-374)
-    if (p.res_mode == CSK_RES_CONV) {
+    if (conv_res) {
         const int fa = p.stride * ta + p.res_off;
         const int span = (p.stride * (tb - ta) + 1) * V;
         const float *seg_base = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
@@ -112,53 +145,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         bs.setup(fa * V, span, p.Tres * V, lane);
         ws.issue(wbase);
         bs.issue(seg_base, p.Cres, cs, 0, wave);
-        for (int c0 = 0; c0 < p.CresPad; c0 += KC) {
+        int c0 = 0;
+        for (; c0 + KC < p.CresPad; c0 += KC) {
             __syncthreads();
             ws.commit(Wl);
             bs.commit(Bl, p.ldb, wave);
             __syncthreads();
-            if (c0 + KC < p.CresPad) {
-                ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
-                bs.issue(seg_base, p.Cres, cs, c0 + KC, wave);
-            }
+            ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
+            bs.issue(seg_base, p.Cres, cs, c0 + KC, wave);
             mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
         }
+        __syncthreads();
+        ws.commit(Wl);
+        bs.commit(Bl, p.ldb, wave);
+        __syncthreads();
+        issue_epilogue_loads();
+        mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
     }
-    // ---- epilogue: + bias (+ identity residual), ReLU, store.  C/D map: col = lane&31, row = (g&3)+8(g>>2)+4(lane>>5)
-    // Loads are unconditional (clamped indices; bias is padded to Mpad) and batched 16 deep; only the stores
-    // are predicated.
-    float *oseg = p.out + (int64_t)seg * p.Cout * Q;
-    const float *rseg = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
-    const int64_t rcs = (int64_t)p.Tres * V;
-    const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
+    // ---- epilogue: + bias (+ identity residual), ReLU, predicated stores.
+    // C/D map: col = lane&31, row = (g&3) + 8(g>>2) + 4(lane>>5)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int q = q0 + wn * 64 + ni * 32 + l31;
         const bool qv = q < Q;
-        const int qc = min(q, Q - 1);
-        int qres = 0;
-        if (ident) {
-            const int t = div_magic(qc, p.vmagic);
-            qres = (t * p.stride + p.res_off) * V + (qc - t * V);
-        }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
-            float bv[16], rv[16];
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                bv[g] = p.bias[co];
-                rv[g] = ident ? rseg[(int64_t)min(co, p.Cout - 1) * rcs + qres] : 0.f;
-            }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                float v = acc[mi][ni][g] + bv[g] + rv[g];
+                const int co = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                float v = acc[mi][ni][g] + bv[mi][g] + rv[ni][mi][g];
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (qv && co < p.Cout) oseg[(int64_t)co * Q + q] = v;
             }
-        }
+    }
+    if (p.stamps && tid == 0) {
+        unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 6;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+        o[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
     }
 }
 
@@ -558,7 +584,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.stride = stride; p.pad = pad;
     p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD);
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
-    { const char *d = getenv("CSK_DEBUG"); p.debug = d ? atoi(d) : 0; }
+    { const char *d = getenv("CSK_STAMPS"); p.stamps = d ? (unsigned long long *)strtoull(d, nullptr, 0) : nullptr; }
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const int max_dt = (NT + V - 2) / V;
