@@ -164,19 +164,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     }
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: + bias (+ identity residual), ReLU, predicated stores.
-    // C/D map: col = lane&31, row = (g&3) + 8(g>>2) + 4(lane>>5)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = q0 + wn * 64 + ni * 32 + l31;
-        const bool qv = q < Q;
+    // C/D map: col = lane&31, row = (g&3) + 8(g>>2) + 4(lane>>5).  A plain store of accumulator register g
+    // writes two 128-B half rows (rows r and r+4).  v_permlane32_swap of the ni=0 / ni=1 registers gives each
+    // lane half the SAME row instead: lanes 0-31 columns 0-31, lanes 32-63 columns 32-63 of row r (first
+    // result) and of row r+4 (second) -> every store instruction writes one 256-B contiguous row segment.
+    {
+        const int qb = q0 + wn * 64 + lane;                    // column of this lane after the swap
+        const bool qv = qb < Q;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int co = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
-                float v = acc[mi][ni][g] + bv[mi][g] + rv[ni][mi][g];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (qv && co < p.Cout) oseg[(int64_t)co * Q + q] = v;
+                const int co_own = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
+                float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                // sw[0]: row (co_own - 4*kh), this lane's column qb; sw[1]: row (co_own - 4*kh + 4)
+                const int row0 = co_own - 4 * kh;
+                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * Q + qb] = __uint_as_float(sw[0]);
+                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * Q + qb] = __uint_as_float(sw[1]);
             }
     }
     if (p.stamps && tid == 0) {
