@@ -123,37 +123,34 @@ def step_flops_per_cycle(nm, c_in=3, V=25):
     return 2 * g * nm, 2 * t * nm
 
 
-def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist):
+def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1):
     """CoST-GCN online inference: `streams` concurrent streams per GPU, persistent ring-buffer state; one
-    cycle = 4 consecutive frames (the stack's stride pattern) = one prediction per stream."""
-    net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
-    randomise_(net, seed=0)
-    net = net.to(dev)
+    cycle = 4 consecutive frames (the stack's stride pattern) = one prediction per stream.  With shards > 1 the
+    stream axis is split into independent shards advanced on separate HIP streams (parallel.StreamShards)."""
+    def make():
+        net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+        randomise_(net, seed=0)
+        return net.to(dev)
+    eng = parallel.StreamShards(make, streams, shards, dev)
     g = torch.Generator(device=dev).manual_seed(200 + rank)
     frames = torch.rand((8, streams, NTU["C"], NTU["V"], NTU["M"]), device=dev, generator=g)   # resident inputs
-    net.warm_up(streams, dev)                               # 76 frames (models/base.py:144-159)
-    for _ in range(75 - 19 - 1):                            # fill the temporal pool so every cycle predicts
-        for f in range(4):
-            net.forward_step(frames[f])
+    for t in range(76 + 4 * (75 - 19 - 1)):     # 76 warm-up frames (models/base.py:144-159) + fill the temporal pool
+        eng.forward_cycle([frames[t % 8]])
     fi = 0
 
     def cycle():
         nonlocal fi
-        out = None
-        for _ in range(4):
-            o = net.forward_step(frames[fi % 8])
-            fi += 1
-            out = o if o is not None else out
+        out = eng.forward_cycle([frames[(fi + f) % 8] for f in range(4)])     # 4 frames, one launch pair per block
+        fi += 4
         return parallel.all_gather_logits(out) if world > 1 else out
 
-    timers = [LaunchTimer(pkg, "tcn_step_launch")]
-    with timers[0] as lt:
+    with LaunchTimer(pkg, "tcn_step_launch") as lt:
         for _ in range(warm_cycles):
             out = cycle()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        lt.enabled = True
+        lt.enabled = shards == 1            # per-launch events are only meaningful without concurrent shards
         t0 = time.perf_counter()
         for _ in range(cycles):
             out = cycle()
@@ -164,7 +161,7 @@ def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, paral
         lt.enabled = False
         tcn_ms, n_launch = lt.total_ms(), len(lt.records)
     assert out is not None and out.shape == (streams * world, NTU["classes"]) and bool(torch.isfinite(out).all())
-    return dt, tcn_ms, n_launch, net.state_bytes()
+    return dt, tcn_ms, n_launch, eng.state_bytes()
 
 
 def cpu_baseline_step(seed):
@@ -211,6 +208,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--streams", type=int, default=1024, help="concurrent CoST-GCN streams per GPU")
     ap.add_argument("--step-cycles", type=int, default=16, help="timed 4-frame cycles of the online workload")
+    ap.add_argument("--stream-shards", type=int, default=2, help="independent stream shards on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -305,13 +303,19 @@ def main():
         }
 
     if do_step:
-        sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist)
+        sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist, args.stream_shards)
         sdt = max_over_ranks(sdt)
+        if args.stream_shards > 1:      # kernel-level timing needs launches that do not overlap: short single-shard pass
+            torch.cuda.empty_cache()
+            _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1)
+            kcycles = 4
+        else:
+            kcycles = args.step_cycles
         gfl, tfl = step_flops_per_cycle(args.streams * NTU["M"])
         fps = 4 * args.streams * world * args.step_cycles / sdt
-        ach = tfl * args.step_cycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0
+        ach = tfl * kcycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0
         step_info = {"metric": "skeleton frames/sec (CoST-GCN online step, NTU-60 shape)", "value": round(fps, 1),
-                     "unit": "frames/s", "streams_per_gpu": args.streams, "ms_per_frame_step": round(sdt / args.step_cycles / 4 * 1e3, 4),
+                     "unit": "frames/s", "streams_per_gpu": args.streams, "stream_shards": args.stream_shards, "frames_per_launch": 4, "ms_per_frame_step": round(sdt / args.step_cycles / 4 * 1e3, 4),
                      "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
                      "roofline": {"bound": "mfma", "kernel": "tcn_step_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,

@@ -13,9 +13,11 @@ Protocol (anchored on the reference's tests, see oracle/stgcn_oracle.py:CoBlockO
   * the emission of step s equals the clip block's output at t = (s - delay) / S;
   * ``forward_steps(x, pad_end)``: all frames, optionally flushed with ``padding`` zero post-GCN frames;
   * ``clean_state()`` zeroes the window (zero state == the clip conv's left zero padding).
-State layout (channel-major, see include/cskel.h): per block a y ring [k][C_out][P] and an output ring
-[5][C_out][P]; the output ring of block l is the input/residual history of block l+1, so the
-residual FIFO (``co.Delay``) costs no copy.
+State layout (channel-major, see include/cskel.h): per block a y ring [12][C_out][P] and an output ring
+[8][C_out][P]; the output ring of block l is the input/residual history of block l+1, so the
+residual FIFO (``co.Delay``) costs no copy.  ``engine_advance`` consumes up to 4 frames per call (one
+stride cycle of the 10-block stack) with one GCN launch and one multi-emission TCN launch per block,
+which is what fills the GPU at ~1000 streams; per-frame stepping is the same code with r = 1.
 """
 import math
 from collections import OrderedDict
@@ -29,7 +31,9 @@ from .blocks import (GraphConvolution, SpatioTemporalBlock, TemporalConvolution,
                      init_weights, unity, zero)
 from .models import layer_table
 
-HIST = 5     # depth of an input / output history ring: residual lag (k-1)/2 = 4 frames + the new one
+HIST = 8     # depth of an input / output history ring (>= residual lag 4 + the frames of one 4-frame cycle)
+YRING = 12   # depth of the post-GCN ring: k-1 = 8 window frames + up to 4 new frames per launch
+MAX_CYCLE = 4
 
 
 def _round4(n: int) -> int:
@@ -70,9 +74,9 @@ class CoTemporalConvolution(TemporalConvolution):
         ops = self._packed_ops(self._ring.device)
         out = torch.empty((ops["c_out"], p), device=self._ring.device, dtype=torch.float32)
         rc = native.lib().csk_tcn_step_f32(
-            native.ptr(self._ring), self.kernel_size, self._s % self.kernel_size, native.ptr(ops["w"]), None, None,
-            native.ptr(ops["bias"]), native.ptr(out), ops["c_in"], ops["c_out"], p, self.kernel_size, 0, 0, 0,
-            native.stream_of(out))
+            native.ptr(self._ring), self.kernel_size, self._s % self.kernel_size, 0, 1, native.ptr(ops["w"]),
+            None, 0, 0, 0, None, native.ptr(ops["bias"]), native.ptr(out), 1, 0,
+            ops["c_in"], ops["c_out"], p, self.kernel_size, 0, 0, 0, native.stream_of(out))
         native.check(rc, "csk_tcn_step_f32")
         return out[:, : n * v].view(-1, n, v).permute(1, 0, 2).contiguous()
 
@@ -109,7 +113,7 @@ class _BlockState:
 
     def __init__(self, c_in, c_out, k, p, device, xin=None):
         self.p = p
-        self.y = torch.zeros((k, c_out, p), device=device, dtype=torch.float32)
+        self.y = torch.zeros((YRING, c_out, p), device=device, dtype=torch.float32)
         self.out = torch.zeros((HIST, c_out, p), device=device, dtype=torch.float32)
         self.owns_xin = xin is None
         self.xin = torch.zeros((HIST, c_in, p), device=device, dtype=torch.float32) if xin is None else xin
@@ -200,32 +204,47 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         if self._state is not None:
             self._state.zero_()
 
-    def engine_step(self, n_frames: int, V: int, flush: bool = False) -> Optional[int]:
-        """Advance by one frame that is already in ``xin[s % HIST]`` (channel-major).  Returns the slot of
-        the output ring that received this step's emission, or None.  ``flush`` pushes a zero post-GCN
-        frame instead (end padding)."""
+    def engine_advance(self, r: int, n_frames: int, V: int, flush: bool = False):
+        """Consume ``r`` (<= 4) frames already stored in ``xin[(s .. s+r-1) % HIST]`` (channel-major).  Returns
+        ``(first_out_slot, n_emit)`` for the emissions of these frames, or None.  ``flush`` pushes zero
+        post-GCN frames instead (end padding)."""
         st, k = self._state, self.kernel_size
-        s = st.s
-        y_slot = st.y[s % k]
-        if flush:
-            y_slot.zero_()
-        else:
-            gops = self.gcn._packed_ops(y_slot.device)
-            gcn_stage(st.xin[s % HIST], y_slot, gops, n_seg=1, frames=n_frames, x_strides=(0, st.p), y_strides=(0, st.p))
-        slot = None
-        if s >= self.delay and (s - self.delay) % self.stride == 0:
-            ops = self._packed_ops(y_slot.device)
-            lag = (k - 1) // 2          # emission s pairs with input frame s - 4 (co.Delay / residual_shrink)
-            mode = {"none": 0, "identity": 1, "conv": 2}[self.kind]
-            xres = st.xin[(s - lag) % HIST] if mode else None
-            slot = st.e % HIST
-            blocks.tcn_step_launch(
-                native.ptr(st.y), k, s % k, native.ptr(ops["w"]), native.ptr(xres), native.ptr(ops["w_res"]),
-                native.ptr(ops["bias"]), native.ptr(st.out[slot]), self.out_channels, self.out_channels, st.p, k,
-                mode, self.in_channels if mode else 0, 1, native.stream_of(st.y))
-            st.e += 1
-        st.s += 1
-        return slot
+        if not 1 <= r <= MAX_CYCLE:
+            raise ValueError(f"engine_advance handles 1..{MAX_CYCLE} frames per call, got {r}")
+        s0, p = st.s, st.p
+        f = 0
+        while f < r:                               # per-frame graph conv, one launch per non-wrapping slot run
+            s = s0 + f
+            run = min(r - f, HIST - s % HIST, YRING - s % YRING)
+            if flush:
+                st.y[s % YRING: s % YRING + run].zero_()
+            else:
+                gops = self.gcn._packed_ops(st.y.device)
+                gcn_stage(st.xin[s % HIST], st.y[s % YRING], gops, n_seg=run, frames=n_frames,
+                          x_strides=(self.in_channels * p, p), y_strides=(self.out_channels * p, p))
+            f += run
+        first = next((s for s in range(s0, s0 + r) if s >= self.delay and (s - self.delay) % self.stride == 0), None)
+        st.s += r
+        if first is None:
+            return None
+        n_emit = (s0 + r - 1 - first) // self.stride + 1
+        ops = self._packed_ops(st.y.device)
+        lag = (k - 1) // 2              # emission s pairs with input frame s - 4 (co.Delay / residual_shrink)
+        mode = {"none": 0, "identity": 1, "conv": 2}[self.kind]
+        slot0 = st.e % HIST
+        blocks.tcn_step_launch(
+            native.ptr(st.y), YRING, first % YRING, self.stride, n_emit, native.ptr(ops["w"]),
+            native.ptr(st.xin) if mode else None, HIST, (first - lag) % HIST, self.stride,
+            native.ptr(ops["w_res"]), native.ptr(ops["bias"]), native.ptr(st.out), HIST, slot0,
+            self.out_channels, self.out_channels, p, k, mode, self.in_channels if mode else 0, 1,
+            native.stream_of(st.y))
+        st.e += n_emit
+        return slot0, n_emit
+
+    def engine_step(self, n_frames: int, V: int, flush: bool = False) -> Optional[int]:
+        """One frame; returns the output-ring slot of this step's emission or None."""
+        res = self.engine_advance(1, n_frames, V, flush)
+        return None if res is None else res[0]
 
     # ---- continual interface on (N, C, V) frames (module boundary: converts layouts) ------------
     def _ensure_state(self, n, v, device):
@@ -345,28 +364,38 @@ class CoStGcn(_Folded):
             self._frames = self._feats = 0
 
     # ---- stepping ------------------------------------------------------------------------------------
+    def features_cycle(self, frames):
+        """``frames``: sequence of 1..4 tensors (N, C, V, M).  Runs data_bn + the ten blocks for all of them
+        (one GCN + one TCN launch per block).  Returns (first_slot, n_emit) of layer 10's output ring or None."""
+        self._require_eval()
+        x0 = frames[0]
+        native.require_device_f32(x0, "CoStGcn frame")
+        n, c, v, m = x0.shape
+        if (c, v, m) != (self.input_shape[0], self.input_shape[2], self.input_shape[3]):
+            raise RuntimeError(f"frame shape {tuple(x0.shape)} does not match input_shape {self.input_shape}")
+        if self._n != n or self._xin0.device != x0.device:           # clean_state_on_shape_change (base.py:161-164)
+            self._bind(n, x0.device)
+        ops = self._packed_ops(x0.device)
+        for x_t in frames:
+            native.require_device_f32(x_t, "CoStGcn frame")
+            dst = self._xin0[self._frames % HIST]
+            # reshape1 + data_bn + reshape2 (base.py:73-82) straight into the channel-major input ring
+            rc = native.lib().csk_input_norm_f32(native.ptr(x_t), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
+                                                 native.ptr(dst), n, c, 1, v, m, v, self._p, native.stream_of(x_t))
+            native.check(rc, "csk_input_norm_f32")
+            self._frames += 1
+        r, res = len(frames), None
+        for i in range(10):
+            res = self.layers[f"layer{i + 1}"].engine_advance(r, n * m, v)
+            if res is None:
+                return None
+            r = res[1]
+        return res
+
     def features_step(self, x_t):
         """(N, C, V, M) frame -> slot of layer 10's output ring holding this step's emission, or None."""
-        self._require_eval()
-        native.require_device_f32(x_t, "CoStGcn frame")
-        n, c, v, m = x_t.shape
-        if (c, v, m) != (self.input_shape[0], self.input_shape[2], self.input_shape[3]):
-            raise RuntimeError(f"frame shape {tuple(x_t.shape)} does not match input_shape {self.input_shape}")
-        if self._n != n or self._xin0.device != x_t.device:          # clean_state_on_shape_change (base.py:161-164)
-            self._bind(n, x_t.device)
-        ops = self._packed_ops(x_t.device)
-        dst = self._xin0[self._frames % HIST]
-        # reshape1 + data_bn + reshape2 (base.py:73-82) straight into the channel-major input ring
-        rc = native.lib().csk_input_norm_f32(native.ptr(x_t), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
-                                             native.ptr(dst), n, c, 1, v, m, v, self._p, native.stream_of(x_t))
-        native.check(rc, "csk_input_norm_f32")
-        self._frames += 1
-        slot = None
-        for i in range(10):
-            slot = self.layers[f"layer{i + 1}"].engine_step(n * m, v)
-            if slot is None:
-                return None
-        return slot
+        res = self.features_cycle([x_t])
+        return None if res is None else res[0]
 
     def _head_step(self, slot, n):
         """spatial_pool -> co.AvgPool1d window -> co.Linear (base.py:84-101)."""
@@ -394,6 +423,18 @@ class CoStGcn(_Folded):
             raise NotImplementedError("update_state=False is not supported on the persistent-state path")
         slot = self.features_step(x_t)
         return None if slot is None else self._head_step(slot, x_t.shape[0])
+
+    def forward_cycle(self, frames):
+        """Up to 4 consecutive frames in one go (list of (N, C, V, M) tensors): same results as calling
+        ``forward_step`` on each, with 4x fewer and 4x larger launches.  Returns the list of logits emitted."""
+        res = self.features_cycle(list(frames))
+        outs = []
+        if res is not None:
+            for j in range(res[1]):
+                o = self._head_step((res[0] + j) % HIST, frames[0].shape[0])
+                if o is not None:
+                    outs.append(o)
+        return outs
 
     def forward_steps(self, x, pad_end=False, update_state=True):
         """(N, C, T, V, M) -> (N, classes, n_predictions) (empty last dim if nothing was emitted)."""

@@ -47,10 +47,11 @@ struct RingStage {
 };
 
 struct StepParams {
-    const float *ring, *w, *xres, *wres, *bias;
+    const float *ring, *w, *xres, *wres, *bias;     // xres / out are RING bases; slots are picked per emission
     float *out;
-    int C, Cpad, Cout, Mpad, K, slots, head;
+    int C, Cpad, Cout, Mpad, K, slots, head, head_step;
     int res_mode, Cres, CresPad, relu;
+    int xres_slots, xres_slot0, xres_step, out_slots, out_slot0;
     int64_t P;
 };
 
@@ -67,10 +68,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     const int l31 = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.y * MT, p0 = blockIdx.x * NT;
     const int64_t P = p.P;
+    // emission j of this launch (blockIdx.z): newest frame in slot head + j*head_step, residual frame in
+    // xres slot xres_slot0 + j*xres_step, output into out slot out_slot0 + j (all modulo their ring depths)
+    const int j = blockIdx.z;
+    const int head = (p.head + j * p.head_step) % p.slots;
+    const float *xres = p.xres + (int64_t)((p.xres_slot0 + j * p.xres_step) % p.xres_slots) * p.Cres * P;
+    float *out = p.out + (int64_t)((p.out_slot0 + j) % p.out_slots) * p.Cout * P;
     const float *slot_base[9];              // uniform: tap r reads ring slot (head - (K-1) + r) mod slots
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-        int slot = (p.head - (p.K - 1) + min(r, p.K - 1)) % p.slots;
+        int slot = (head - (p.K - 1) + min(r, p.K - 1)) % p.slots;
         if (slot < 0) slot += p.slots;
         slot_base[r] = p.ring + (int64_t)slot * p.C * P + p0;
     }
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     }
     // ---- phase 2: 1x1 residual conv on the delayed block input (CoTempConv k=1 + co.Delay, base.py:424-441)
     if (p.res_mode == CSK_RES_CONV) {
-        slot_base[0] = p.xres + p0;
+        slot_base[0] = xres + p0;
         const float *wbase = p.wres + m0;
         ws.setup(1, p.CresPad, p.Mpad, tid);
         ws.issue(wbase);
@@ -140,14 +147,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
             for (int g = 0; g < 16; ++g) {
                 const int co = cb + (g & 3) + 8 * (g >> 2);
                 bv[g] = p.bias[co];
-                rv[g] = ident ? p.xres[(int64_t)min(co, p.Cout - 1) * P + qc] : 0.f;
+                rv[g] = ident ? xres[(int64_t)min(co, p.Cout - 1) * P + qc] : 0.f;
             }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int co = cb + (g & 3) + 8 * (g >> 2);
                 float v = acc[mi][ni][g] + bv[g] + rv[g];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (qv && co < p.Cout) p.out[(int64_t)co * P + q] = v;
+                if (qv && co < p.Cout) out[(int64_t)co * P + q] = v;
             }
         }
     }
@@ -186,15 +193,20 @@ __global__ void co_window_mean_kernel(const float *__restrict__ ring, float *__r
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, const float *w, const float *x_res,
-                                const float *w_res, const float *bias, float *out, int c, int c_out, int64_t P,
-                                int k, int res_mode, int c_res, int relu, void *stream) {
+extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head_step, int n_emit, const float *w,
+                                const float *x_res, int x_res_slots, int x_res_slot0, int x_res_step,
+                                const float *w_res, const float *bias, float *out, int out_slots, int out_slot0,
+                                int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, void *stream) {
     if (!ring || !w || !bias || !out) CSK_FAIL("tcn_step: null pointer");
     if (c <= 0 || c_out <= 0 || P < 4 || (P & 3)) CSK_FAIL("tcn_step: bad dims (P must be a positive multiple of 4)");
     if (k < 1 || k > 9 || slots < k || head < 0 || head >= slots) CSK_FAIL("tcn_step: bad k/slots/head");
+    if (n_emit < 1 || n_emit > 64 || head_step < 0 || out_slots < n_emit || out_slot0 < 0 || out_slot0 >= out_slots)
+        CSK_FAIL("tcn_step: bad emission geometry");
+    if (slots < k - 1 + (n_emit - 1) * head_step + 1) CSK_FAIL("tcn_step: ring too shallow for %d emissions", n_emit);
     if (P >= (1ll << 31) - 256) CSK_FAIL("tcn_step: P too large");
     if (res_mode != CSK_RES_NONE) {
         if (!x_res) CSK_FAIL("tcn_step: residual requested without x_res");
+        if (x_res_slots < 1 || x_res_slot0 < 0 || x_res_slot0 >= x_res_slots || x_res_step < 0) CSK_FAIL("tcn_step: bad residual ring geometry");
         if (res_mode == CSK_RES_IDENTITY && c_res != c_out) CSK_FAIL("tcn_step: identity residual needs c_res == c_out");
         if (res_mode == CSK_RES_CONV && !w_res) CSK_FAIL("tcn_step: conv residual without w_res");
     }
@@ -202,12 +214,14 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, const fl
     StepParams p;
     p.ring = ring; p.w = w; p.xres = x_res ? x_res : ring; p.wres = w_res; p.bias = bias; p.out = out;
     p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
-    p.K = k; p.slots = slots; p.head = head; p.res_mode = res_mode;
+    p.K = k; p.slots = slots; p.head = head; p.head_step = head_step; p.res_mode = res_mode;
     p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD); p.relu = relu; p.P = P;
+    p.xres_slots = x_res ? x_res_slots : 1; p.xres_slot0 = x_res ? x_res_slot0 : 0; p.xres_step = x_res_step;
+    p.out_slots = out_slots; p.out_slot0 = out_slot0;
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const size_t lds = (size_t)(9 * KC * MT + 9 * KC * NT) * sizeof(float);   // always 9 taps (73.7 KB)
-    dim3 grid((unsigned)((P + NT - 1) / NT), p.Mpad / MT);
+    dim3 grid((unsigned)((P + NT - 1) / NT), p.Mpad / MT, n_emit);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (big) {

@@ -40,3 +40,38 @@ def all_gather_ragged(local: torch.Tensor, n_total: int, group=None) -> torch.Te
     padded[: local.shape[0]] = local
     gathered = all_gather_logits(padded, group).view(world, width, *local.shape[1:])
     return torch.cat([gathered[r, : sizes[r]] for r in range(world)], dim=0)
+
+
+class StreamShards:
+    """Intra-GPU sharding of the continual stream axis over HIP streams.
+
+    At ~1000 streams a block's launch has ~800 workgroups for 512 resident slots (1.56 rounds), so the second
+    round runs 56 % full.  Streams are independent, so the stream axis is cut into ``n_shards`` contiguous
+    shards, each with its own model instance / state slab, advanced on its own HIP stream: the partially filled
+    tail round of one shard's launch overlaps the other shards' launches.  Results are identical to one big
+    shard (no cross-stream arithmetic).  ``make_model`` builds one (already-on-device, eval) CoStGcn."""
+
+    def __init__(self, make_model, n_streams: int, n_shards: int, device):
+        self.bounds = [shard_bounds(n_streams, r, n_shards) for r in range(n_shards)]
+        self.models = [make_model() for _ in range(n_shards)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_shards)] if n_shards > 1 else [None]
+        self.device = device
+
+    def forward_cycle(self, frames):
+        """frames: list of (N, C, V, M) tensors -> concatenated logits of the last emission (or None)."""
+        if len(self.models) == 1:
+            outs = self.models[0].forward_cycle(frames)
+            return outs[-1] if outs else None
+        cur = torch.cuda.current_stream(self.device)
+        parts = []
+        for (lo, hi), model, st in zip(self.bounds, self.models, self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs = model.forward_cycle([f[lo:hi] for f in frames])
+                parts.append(outs[-1] if outs else None)
+        for st in self.streams:
+            cur.wait_stream(st)
+        return None if any(p is None for p in parts) else torch.cat(parts, dim=0)
+
+    def state_bytes(self):
+        return sum(m.state_bytes() for m in self.models)

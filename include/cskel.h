@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 1
+#define CSK_ABI_VERSION 2
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -116,16 +116,21 @@ int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *l
  * ------------------------------------------------------------------------------------------------ */
 
 /*
- * One emitting step of CoTemporalConvolution (+ residual + ReLU of CoSpatioTemporalBlock, base.py:412-446):
- *     out[co, p] = ReLU( sum_r sum_c W[r][c][co] * ring[(head-(k-1)+r) mod slots][c][p] + bias[co] + res[co, p] )
- *  ring   [slots][c][P] post-GCN frames, `head` = slot of the newest frame; zero-initialised slots act as the
- *         clip conv's zero padding.   slots >= k.
- *  x_res  (c_res, P) the block input delayed by (k-1)/2 steps (co.Delay), or NULL;  w_res as in csk_tcn_stage_f32.
- *  out    (c_out, P).   All frame pointers 16-byte aligned, P % 4 == 0.
+ * Emitting step(s) of CoTemporalConvolution (+ residual + ReLU of CoSpatioTemporalBlock, base.py:412-446).
+ * For emission j = 0 .. n_emit-1 (one grid.z slice each; n_emit > 1 batches the frames of a stride cycle):
+ *     h_j   = (head + j*head_step) mod slots                       slot of the newest post-GCN frame
+ *     out_j[co, p] = ReLU( sum_r sum_c W[r][c][co] * ring[(h_j-(k-1)+r) mod slots][c][p] + bias[co] + res_j[co, p] )
+ *  ring   [slots][c][P] post-GCN frames; zero-initialised slots act as the clip conv's zero padding;
+ *         slots >= k + (n_emit-1)*head_step.
+ *  x_res  ring [x_res_slots][c_res][P] of block inputs or NULL; emission j pairs with slot
+ *         (x_res_slot0 + j*x_res_step) mod x_res_slots = the input delayed by (k-1)/2 frames (co.Delay).
+ *  out    ring [out_slots][c_out][P]; emission j is written to slot (out_slot0 + j) mod out_slots.
+ *  All ring bases 16-byte aligned, P % 4 == 0.
  */
-int csk_tcn_step_f32(const float *ring, int slots, int head, const float *w, const float *x_res,
-                     const float *w_res, const float *bias, float *out, int c, int c_out, int64_t P, int k,
-                     int res_mode, int c_res, int relu, void *stream);
+int csk_tcn_step_f32(const float *ring, int slots, int head, int head_step, int n_emit, const float *w,
+                     const float *x_res, int x_res_slots, int x_res_slot0, int x_res_step,
+                     const float *w_res, const float *bias, float *out, int out_slots, int out_slot0,
+                     int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, void *stream);
 
 /* spatial_pool of CoModelBase (models/base.py:84) on a channel-major frame: feat[n, c] = mean of the MV = M*V
  * positions of stream n.  h (C, P); feat (N, C). */

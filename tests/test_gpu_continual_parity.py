@@ -143,3 +143,25 @@ def test_costgcn_logits_vs_oracle_and_forward_modes():
     frame = co.forward(xd, forward_mode="frame").cpu()
     clip = co.forward(xd, forward_mode="clip").cpu()
     assert frame.shape == (1, 60) and max_err(frame, clip) <= TOL
+
+
+def test_forward_cycle_equals_per_frame_stepping():
+    """Batching the frames of a stride cycle into one launch per block must not change a single bit, for
+    aligned cycles of 4, ragged cycle lengths and cycles that wrap the ring buffers."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:1, :, :130].to(DEV)
+    ref = pkg.CoStGcn(A, pool_size=5, pool_padding=1).eval()
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.to(DEV)
+    want = [o for o in (ref.forward_step(x[:, :, t].contiguous()) for t in range(x.shape[2])) if o is not None]
+    for pattern in ([4], [3, 4, 1, 2], [1, 4, 4, 3]):
+        co = pkg.CoStGcn(A, pool_size=5, pool_padding=1).eval()
+        co.load_state_dict(sd, strict=True)
+        co = co.to(DEV)
+        got, t, i = [], 0, 0
+        while t < x.shape[2]:
+            r = min(pattern[i % len(pattern)], x.shape[2] - t)
+            got += co.forward_cycle([x[:, :, t + f].contiguous() for f in range(r)])
+            t, i = t + r, i + 1
+        assert len(got) == len(want) and len(want) >= 8
+        assert all(torch.equal(g, w) for g, w in zip(got, want)), pattern
