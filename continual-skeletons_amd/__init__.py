@@ -25,6 +25,7 @@ from .continual import (  # noqa: F401
     CoStGcn,
     CoTemporalConvolution,
 )
+from .agcn import AdaptiveGraphConvolution, AGcn, CoAdaptiveGraphConvolution, CoAGcn  # noqa: F401
 from . import native  # noqa: F401
 
 # names used by BASELINE.json:north_star
@@ -35,6 +36,7 @@ CoStGcnBlock = CoSpatioTemporalBlock
 __all__ = [
     "Graph", "ntu_graph", "kinetics_graph", "GraphConvolution", "TemporalConvolution",
     "SpatioTemporalBlock", "SpatialGraphConv", "StGcnBlock", "CoStGcnBlock", "StGcn", "CoStGcn",
-    "CoGraphConvolution", "CoTemporalConvolution", "CoSpatioTemporalBlock", "init_weights", "zero", "unity",
+    "CoGraphConvolution", "CoTemporalConvolution", "CoSpatioTemporalBlock",
+    "AdaptiveGraphConvolution", "CoAdaptiveGraphConvolution", "AGcn", "CoAGcn", "init_weights", "zero", "unity",
     "native",
 ]

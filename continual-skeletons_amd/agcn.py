@@ -1,0 +1,107 @@
+"""A-GCN adaptive graph convolution and the (Co)AGCN model drivers (BASELINE.json configs[3]).
+
+Counterpart of ``AdaptiveGraphConvolution`` (models/a_gcn/a_gcn.py:12-69), ``AGcn`` (a_gcn.py:72-145) and
+``CoAGcn`` (models/coa_gcn/coa_gcn.py).  The graph conv aggregates with a PER-SAMPLE dense adjacency
+    adj_i = softmax_{dim=-2}( a_i(x)^T b_i(x) / (inter*T) ) + (A + graph_attn)_i        (a_gcn.py:50-63)
+Three launches: (1) the six 1x1 embedding convs as ONE fused 1x1 conv (tcn stage / step kernel), (2)
+``csk_agcn_attention_f32`` -> dense column-wise adjacency values per sample, (3) the general GCN stage kernel
+with ``adj_seg_stride`` (aggregation on VALU from LDS-staged tables, channel mixing on MFMA).
+Clip mode: one V x V matrix per sample over all T; continual mode (CoAGCN): T = 1, i.e. per-frame attention --
+clip != step by design (a_gcn.py:60-61, coa_gcn.py:31).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import blocks, fold, native
+from .blocks import GraphConvolution, SpatioTemporalBlock, _check_input, init_weights
+from .continual import CoSpatioTemporalBlock, CoStGcn
+from .models import StGcn
+
+
+class AdaptiveGraphConvolution(GraphConvolution):
+    def __init__(self, in_channels, out_channels, A, bn_momentum=0.1, coff_embedding=4):
+        super().__init__(in_channels, out_channels, A, bn_momentum)
+        self.inter_c = out_channels // coff_embedding
+        self.a_conv = nn.ModuleList(nn.Conv2d(in_channels, self.inter_c, 1) for _ in range(self.num_subset))
+        self.b_conv = nn.ModuleList(nn.Conv2d(in_channels, self.inter_c, 1) for _ in range(self.num_subset))
+        for m in list(self.a_conv) + list(self.b_conv):
+            init_weights(m)
+        self.soft = nn.Softmax(-2)
+
+    def _fold(self):
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        f = fold.fold_graph_conv(sd)                      # weights / bias as for GraphConvolution ...
+        v = f["V"]
+        # ... but the adjacency is dense and per sample: index pattern 0..V-1 for every column
+        f["ell_src"] = torch.arange(v, dtype=torch.int32).repeat(3, v, 1).contiguous()
+        f["ell_cnt_host"] = torch.tensor([v, v, v], dtype=torch.int32)
+        f["ell_w"] = v
+        f["ell_val"] = None
+        f["a_sum"] = (sd["A"].double() + sd["graph_attn"].double()).float().contiguous()      # a_gcn.py:50
+        inter, ci = self.inter_c, self.in_channels
+        we = torch.cat([sd[f"a_conv.{i}.weight"] for i in range(3)] + [sd[f"b_conv.{i}.weight"] for i in range(3)], 0)
+        be = torch.cat([sd[f"a_conv.{i}.bias"] for i in range(3)] + [sd[f"b_conv.{i}.bias"] for i in range(3)], 0)
+        f["w_embed"] = fold.pack_conv_weight(we.view(6 * inter, ci, 1, 1), torch.ones(6 * inter, dtype=torch.float64))
+        f["b_embed"] = fold.pad_vec(be.double())
+        return f
+
+    def _attention(self, E, ops, n_seg, T, V, e_seg_stride, e_chan_stride):
+        adj = torch.empty((n_seg, 3, V, V), device=E.device, dtype=torch.float32)
+        rc = native.lib().csk_agcn_attention_f32(native.ptr(E), native.ptr(ops["a_sum"]), native.ptr(adj), n_seg,
+                                                 self.inter_c, T, V, e_seg_stride, e_chan_stride, native.stream_of(E))
+        native.check(rc, "csk_agcn_attention_f32")
+        return adj
+
+    def forward(self, x):
+        self._require_eval()
+        _check_input(x, self.in_channels, "AdaptiveGraphConvolution input")
+        ops = self._packed_ops(x.device)
+        n, c, t, v = x.shape
+        e_ch = 6 * self.inter_c
+        E = blocks.tcn_stage(x, ops["w_embed"], ops["b_embed"], e_ch, 1, 1, 0, relu=False)       # (N, 6*inter, T, V)
+        adj = self._attention(E, ops, n, t, v, e_ch * t * v, t * v)
+        y = torch.empty((n, self.out_channels, t, v), device=x.device, dtype=torch.float32)
+        o = dict(ops, ell_val=adj)
+        blocks.gcn_stage(x, y, o, n_seg=n, frames=t, x_strides=(c * t * v, t * v),
+                         y_strides=(self.out_channels * t * v, t * v), adj_seg_stride=3 * v * v)
+        return y
+
+    def stage(self, x, y, n_seg, frames, x_strides, y_strides):
+        """Continual use on channel-major frames (C, P): every skeleton is its own 'sample' with T = 1, so the
+        adjacency is per frame (coa_gcn.py: forward_stepping of the module).  n_seg ring slots are handled one
+        by one."""
+        ops = self._packed_ops(x.device)
+        v, p = ops["V"], x_strides[1]
+        e_ch = 6 * self.inter_c
+        for j in range(n_seg):
+            xf = x.reshape(-1)[j * x_strides[0]:] if n_seg > 1 else x
+            yf = y.reshape(-1)[j * y_strides[0]:] if n_seg > 1 else y
+            E = torch.empty((e_ch, p), device=x.device, dtype=torch.float32)
+            rc = native.lib().csk_tcn_step_f32(native.ptr(xf), 1, 0, 0, 1, native.ptr(ops["w_embed"]), None, 0, 0, 0, None,
+                                               native.ptr(ops["b_embed"]), native.ptr(E), 1, 0, self.in_channels, e_ch, p,
+                                               1, 0, 0, 0, native.stream_of(x))
+            native.check(rc, "csk_tcn_step_f32")
+            adj = self._attention(E, ops, frames, 1, v, v, p)
+            o = dict(ops, ell_val=adj)
+            blocks.gcn_stage(xf, yf, o, n_seg=frames, frames=1, x_strides=(v, p), y_strides=(v, p),
+                             adj_seg_stride=3 * v * v)
+
+
+def CoAdaptiveGraphConvolution(in_channels, out_channels, A, bn_momentum=0.1):
+    """models/coa_gcn/coa_gcn.py:11-14"""
+    return AdaptiveGraphConvolution(in_channels, out_channels, A, bn_momentum)
+
+
+class AGcn(StGcn):
+    """models/a_gcn/a_gcn.py:72-145: the ST-GCN layer table with AdaptiveGraphConvolution."""
+
+    def __init__(self, graph_A, input_shape=(3, 300, 25, 2), num_classes=60):
+        super().__init__(graph_A, input_shape, num_classes, GraphConv=AdaptiveGraphConvolution)
+
+
+class CoAGcn(CoStGcn):
+    """models/coa_gcn/coa_gcn.py: CoST-GCN stack with the adaptive graph conv applied per frame."""
+
+    def __init__(self, graph_A, input_shape=(3, 300, 25, 2), num_classes=60, pool_size=-1, pool_padding=-1):
+        super().__init__(graph_A, input_shape, num_classes, pool_size, pool_padding, CoGraphConv=CoAdaptiveGraphConvolution)

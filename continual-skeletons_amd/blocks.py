@@ -117,6 +117,10 @@ class GraphConvolution(_Folded):
         gcn_stage(x, y, ops, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v))
         return y
 
+    def stage(self, x, y, n_seg, frames, x_strides, y_strides):
+        """Launch on explicit views/strides (used by the continual engine on its channel-major rings)."""
+        gcn_stage(x, y, self._packed_ops(x.device), n_seg=n_seg, frames=frames, x_strides=x_strides, y_strides=y_strides)
+
 
 def gcn_stage(x, y, ops, n_seg, frames, x_strides, y_strides, adj_seg_stride=0):
     rc = native.lib().csk_gcn_stage_f32(

@@ -219,9 +219,8 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             if flush:
                 st.y[s % YRING: s % YRING + run].zero_()
             else:
-                gops = self.gcn._packed_ops(st.y.device)
-                gcn_stage(st.xin[s % HIST], st.y[s % YRING], gops, n_seg=run, frames=n_frames,
-                          x_strides=(self.in_channels * p, p), y_strides=(self.out_channels * p, p))
+                self.gcn.stage(st.xin[s % HIST], st.y[s % YRING], n_seg=run, frames=n_frames,
+                               x_strides=(self.in_channels * p, p), y_strides=(self.out_channels * p, p))
             f += run
         first = next((s for s in range(s0, s0 + r) if s >= self.delay and (s - self.delay) % self.stride == 0), None)
         st.s += r
@@ -300,13 +299,15 @@ class CoStGcn(_Folded):
     (what ``map_state_dict`` does in the reference, base.py:200-224).
     """
 
-    def __init__(self, graph_A, input_shape=(3, 300, 25, 2), num_classes=60, pool_size=-1, pool_padding=-1):
+    def __init__(self, graph_A, input_shape=(3, 300, 25, 2), num_classes=60, pool_size=-1, pool_padding=-1,
+                 CoGraphConv=CoGraphConvolution):
         super().__init__()
         (c_in, t, v, m) = input_shape
         self.input_shape, self.num_classes = tuple(input_shape), num_classes
         self.data_bn = nn.BatchNorm1d(m * c_in * v)
         self.layers = nn.ModuleDict(OrderedDict(
-            (f"layer{i + 1}", CoSpatioTemporalBlock(ci, co, graph_A, stride=s, residual=r, padding="equal"))
+            (f"layer{i + 1}", CoSpatioTemporalBlock(ci, co, graph_A, stride=s, residual=r, padding="equal",
+                                                    CoGraphConv=CoGraphConv))
             for i, (ci, co, s, r) in enumerate(layer_table(c_in))))
         self.fc = nn.Linear(256, num_classes)
         init_weights(self.data_bn, bs=1)

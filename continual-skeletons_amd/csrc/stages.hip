@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
     {
         const int n = 3 * V * EW;
         const float *gv = p.ell_val + (int64_t)seg * p.adj_seg_stride;
-        const int32_t *gs = p.ell_src + (int64_t)seg * p.adj_seg_stride;
+        const int32_t *gs = p.ell_src;             // the index pattern is shared; only the values are per segment
         for (int e = tid; e < n; e += NTHREADS) {
             Lv[e] = gv[e];
             Ls[e] = gs[e];
@@ -504,6 +504,66 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
 }
 
 // ------------------------------------------------------------------------------------------------
+// A-GCN attention (models/a_gcn/a_gcn.py:53-63): per sample n and subset i
+//     logits[v, w] = sum_{k,t} Ea[i][k][t][v] * Eb[i][k][t][w] / (inter * T)
+//     adj[i][v, w] = softmax over v (dim -2) of logits + (A + graph_attn)[i][v, w]
+// E = (n_seg, 6*inter, T, V): channels [i*inter + k] = a_conv_i, [3*inter + i*inter + k] = b_conv_i (biases
+// included), produced by csk_tcn_stage_f32 as a 1x1 conv.  Output: the column-wise dense ELL values
+// ell_val[n][i][w][v] = adj[i][v, w] consumed by gcn_stage_kernel with adj_seg_stride = 3*V*V.
+// One workgroup per (n, i); rows (k,t) are streamed through LDS, thread p owns pairs (v,w) = p, p+256, p+512.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void agcn_attention_kernel(const float *__restrict__ E, const float *__restrict__ a_sum,
+                                                             float *__restrict__ ell_val, int inter, int T, int V,
+                                                             int64_t e_seg_stride, int64_t e_chan_stride) {
+    constexpr int ROWS = 64;                      // (k,t) rows per LDS pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ea = smem;                             // [ROWS][V]
+    float *Eb = smem + ROWS * V;                  // [ROWS][V]
+    float *L = smem + 2 * ROWS * V;               // [V][V] logits
+    const int n = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
+    const int VV = V * V, K = inter * T;
+    const float *ea = E + (int64_t)n * e_seg_stride + (int64_t)i * inter * e_chan_stride;       // row (k,t) at k*chan + t*V
+    const float *eb = E + (int64_t)n * e_seg_stride + (int64_t)(3 + i) * inter * e_chan_stride;
+    const int TV = T * V;
+    float acc[3] = {0.f, 0.f, 0.f};
+    int pv[3], pw[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int pidx = min(tid + j * 256, VV - 1);
+        pv[j] = pidx / V;
+        pw[j] = pidx % V;
+    }
+    for (int r0 = 0; r0 < K; r0 += ROWS) {
+        const int nr = min(ROWS, K - r0);
+        __syncthreads();
+        for (int e = tid; e < nr * V; e += 256) {
+            const int g = r0 * V + e;                                  // flat (k, t, v) index; k = g / (T*V)
+            const int64_t off = (int64_t)(g / TV) * e_chan_stride + (g % TV);
+            Ea[e] = ea[off];
+            Eb[e] = eb[off];
+        }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = fmaf(Ea[r * V + pv[j]], Eb[r * V + pw[j]], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (tid + j * 256 < VV) L[tid + j * 256] = acc[j] / (float)K;
+    __syncthreads();
+    if (tid < V) {                                // softmax over v for column w = tid
+        const int w = tid;
+        float m = -INFINITY;
+        for (int v = 0; v < V; ++v) m = fmaxf(m, L[v * V + w]);
+        float sum = 0.f;
+        for (int v = 0; v < V; ++v) sum += expf(L[v * V + w] - m);
+        float *dst = ell_val + ((int64_t)(n * 3 + i) * V + w) * V;
+        for (int v = 0; v < V; ++v) dst[v] = expf(L[v * V + w] - m) / sum + a_sum[(i * V + v) * V + w];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pre / post
 // ------------------------------------------------------------------------------------------------
 __global__ void input_norm_kernel(const float *__restrict__ x, const float *__restrict__ scale,
@@ -693,4 +753,14 @@ extern "C" int csk_pool_fc_f32(const float *h, const float *fc_w, const float *f
     if (e != hipSuccess) return (int)e;
     if (logits) return csk_fc_f32(feat, fc_w, fc_b, logits, N, C, classes, stream);
     return 0;
+}
+
+extern "C" int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, int n_seg, int inter, int T,
+                                      int V, int64_t e_seg_stride, int64_t e_chan_stride, void *stream) {
+    if (!E || !a_sum || !ell_val) CSK_FAIL("agcn_attention: null pointer");
+    if (n_seg <= 0 || inter <= 0 || T <= 0 || V < 2 || V > 27) CSK_FAIL("agcn_attention: bad dims (V <= 27)");
+    const size_t lds = (size_t)(2 * 64 * V + V * V) * sizeof(float);
+    hipLaunchKernelGGL(agcn_attention_kernel, dim3(n_seg, 3), dim3(256), lds, (hipStream_t)stream, E, a_sum, ell_val,
+                       inter, T, V, e_seg_stride, e_chan_stride);
+    return (int)hipGetLastError();
 }

@@ -51,8 +51,8 @@ const char *csk_last_error(void);
  *  ell_src  [3][V][ell_w] int32 : row indices v of the non-zeros of column w of A_eff[i] (padded with 0)
  *  ell_val  [3][V][ell_w] fp32  : their values (padded with 0.0)
  *  ell_cnt  [3] : number of meaningful entries per subset (<= ell_w) -- lets sparse subsets skip padding
- *  adj_seg_stride: 0 for a graph shared by all segments (ST-GCN); 3*V*ell_w for per-segment
- *           adjacency (A-GCN's per-sample attention, models/a_gcn/a_gcn.py:62-65).
+ *  adj_seg_stride: 0 for a graph shared by all segments (ST-GCN); 3*V*ell_w for per-segment VALUES
+ *           (A-GCN's per-sample attention, models/a_gcn/a_gcn.py:62-65; ell_src stays shared).
  *  res_mode CSK_RES_IDENTITY (c_in == c_out) or CSK_RES_CONV.
  */
 int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias,
@@ -105,6 +105,18 @@ int csk_pool_fc_f32(const float *h, const float *fc_w, const float *fc_b, float 
 /* plain FC on pooled features: logits[n] = feat[n] @ fc_w^T + fc_b  (co.Linear, models/base.py:99) */
 int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *logits,
                int N, int C, int classes, void *stream);
+
+/*
+ * A-GCN adaptive adjacency, models/a_gcn/a_gcn.py:53-63.  E holds the a_conv / b_conv embeddings of the three
+ * subsets (channels [i*inter+k] = a_conv_i, [(3+i)*inter+k] = b_conv_i, biases included; a 1x1 conv produced by
+ * csk_tcn_stage_f32 (clip) or csk_tcn_step_f32 (continual)); element (n, ch, t, v) at
+ * n*e_seg_stride + ch*e_chan_stride + t*V + v.  For every sample and subset:
+ *     adj[i][v, w] = softmax_v( sum_{k,t} Ea[k,t,v] * Eb[k,t,w] / (inter*T) ) + a_sum[i][v, w],   a_sum = A + graph_attn
+ * written as the dense column-wise ELL values ell_val[n][i][w][v] that csk_gcn_stage_f32 consumes with
+ * ell_w = V, ell_cnt = {V,V,V}, adj_seg_stride = 3*V*V.
+ */
+int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, int n_seg, int inter, int T, int V,
+                           int64_t e_seg_stride, int64_t e_chan_stride, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Continual (frame-by-frame) path.  The arithmetic the reference delegates to the third-party package

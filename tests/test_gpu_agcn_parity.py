@@ -1,0 +1,100 @@
+"""GPU parity of the A-GCN adaptive graph convolution (BASELINE.json configs[3]): golden vectors from the
+reference's AdaptiveGraphConvolution (fixture G7), seeded comparisons against the oracle at real channel counts,
+and the CoAGCN per-frame (T = 1) use inside a continual block."""
+import pytest
+import torch
+
+import _bootstrap
+from oracle import stgcn_oracle as o
+from tests.helpers import load_golden, max_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+pkg = _bootstrap.load()
+DEV = "cuda:0"
+A_KIN = pkg.kinetics_graph().A
+
+
+@pytest.mark.parametrize("tag,ci,co", [("neq", 3, 8), ("eq", 8, 8)])
+@pytest.mark.parametrize("t", [1, 6])
+def test_adaptive_graph_conv_golden(tag, ci, co, t):
+    a, sd = load_golden(f"g7_agcn_{tag}")
+    m = pkg.AdaptiveGraphConvolution(ci, co, A_KIN).eval()
+    m.load_state_dict(sd, strict=True)
+    y = m.to(DEV)(torch.from_numpy(a[f"x_t{t}"]).to(DEV))
+    assert max_err(y.cpu(), a[f"y_t{t}"]) <= TOL
+
+
+def _randomise(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("graph_attn") or ("bn" in name and name.endswith("weight")) or name.endswith("residual.1.weight"):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand(prm.shape, generator=g) - 0.5)
+            elif "a_conv" in name or "b_conv" in name:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.5)       # make the attention non-uniform
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
+
+
+@pytest.mark.parametrize("ci,co,t,v", [(64, 64, 40, 18), (64, 128, 17, 18), (3, 64, 300, 18), (16, 16, 9, 25)])
+def test_adaptive_graph_conv_vs_oracle(ci, co, t, v):
+    A = A_KIN if v == 18 else pkg.ntu_graph().A
+    m = pkg.AdaptiveGraphConvolution(ci, co, A).eval()
+    _randomise(m, 7 + ci + co)
+    sd = {k: v_.clone() for k, v_ in m.state_dict().items()}
+    x = torch.rand(3, ci, t, v, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = o.adaptive_graph_conv(x, sd)
+    got = m.to(DEV)(x.to(DEV)).cpu()
+    assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max()))
+
+
+def test_agcn_block_clip_and_continual():
+    """SpatioTemporalBlock(GraphConv=AdaptiveGraphConvolution) in clip mode, and the CoAGCN block stepping
+    (per-frame attention) against the oracle's continual block built on adaptive_graph_conv."""
+    blk = pkg.SpatioTemporalBlock(8, 8, A_KIN, GraphConv=pkg.AdaptiveGraphConvolution).eval()
+    _randomise(blk, 3)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.rand(2, 8, 24, 18, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        want = o.st_block(x, sd, "", 1, True, gcn=o.adaptive_graph_conv)
+    assert max_err(blk.to(DEV)(x.to(DEV)).cpu(), want) <= TOL
+    co = pkg.CoSpatioTemporalBlock(8, 8, A_KIN, padding=4, CoGraphConv=pkg.CoAdaptiveGraphConvolution).eval()
+    co.load_state_dict(sd, strict=True)
+    co = co.to(DEV)
+    orc = o.CoBlockOracle(sd, "", 1, True, padding=4, gcn=o.adaptive_graph_conv)
+    with torch.no_grad():
+        for t in range(x.shape[2]):
+            w = orc.forward_step(x[:, :, t])
+            g = co.forward_step(x[:, :, t].contiguous().to(DEV))
+            assert (w is None) == (g is None)
+            if w is not None:
+                assert max_err(g.cpu(), w) <= TOL, t
+
+
+def test_coagcn_model_steps_vs_oracle():
+    A = A_KIN
+    net = pkg.CoAGcn(A, input_shape=(3, 300, 18, 2), num_classes=400, pool_size=4, pool_padding=1).eval()
+    _randomise(net, 11)
+    net_sd = net.state_dict()
+    sd = {k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in net_sd.items()}
+    x = torch.rand(1, 3, 96, 18, 2, generator=torch.Generator().manual_seed(4))
+    orc = o.CoStGcnOracle(sd, pool_size=4, pool_padding=1)
+    for b in orc.blocks:
+        b.gcn = o.adaptive_graph_conv
+    want = []
+    with torch.no_grad():
+        for t in range(x.shape[2]):
+            r = orc.forward_step(x[:, :, t])
+            if r is not None:
+                want.append(r)
+    got = net.to(DEV).forward_steps(x.to(DEV)).cpu()
+    want = torch.stack(want, dim=2)
+    assert got.shape == want.shape and got.shape[2] >= 2
+    assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max()))
