@@ -442,12 +442,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
 
     const int offA = wm * 64 + l31;
     const int cpad = p.CinPad;                             // multiple of CSK_CPAD == KCG (zero-padded weights)
-    issue(0);
-    for (int c0 = 0; c0 < cpad; c0 += KCG) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (c0 + KCG < cpad) issue(c0 + KCG);
+    auto mfma_chunk16 = [&]() {
 #pragma unroll 2
         for (int s = 0; s < KCG / 2; ++s) {
             const int kk = 2 * s + kh;
@@ -475,32 +470,53 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][1], acc[1][1], 0, 0, 0);
             }
         }
+    };
+    issue(0);
+    int c0 = 0;
+    for (; c0 + KCG < cpad; c0 += KCG) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        issue(c0 + KCG);
+        mfma_chunk16();
     }
-
-    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+    __syncthreads();                                       // peeled last chunk: the staging registers are dead,
+    commit();                                              // so the epilogue operands are loaded under its MFMAs
+    __syncthreads();
+    float bb[2][16], rv[2][2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) bb[mi][g] = p.bias[m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int q = q0 + wn * 64 + ni * 32 + l31;
-        const bool qv = q < Q;
-        const int qc = min(q, Q - 1);
+        const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
-            float bb[16], rv[16];
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                bb[g] = p.bias[co];
-                rv[g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
+                const int co = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                rv[ni][mi][g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
             }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                const float v = fmaxf(acc[mi][ni][g] + bb[g] + rv[g], 0.f);
-                if (qv && co < p.Cout) oseg[(int64_t)co * p.y_chan_stride + q] = v;
-            }
-        }
     }
+    mfma_chunk16();
+
+    // epilogue: ReLU(acc + bias + identity residual); permlane32_swap pairs the ni = 0/1 registers so that every
+    // store instruction writes one 256-B contiguous row segment (see tcn_stage_kernel)
+    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+    const int qb = q0 + wn * 64 + lane;
+    const bool qv = qb < Q;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row0 = m0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2);
+            const float v0 = fmaxf(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g], 0.f);
+            const float v1 = fmaxf(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g], 0.f);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+            if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = __uint_as_float(sw[0]);
+            if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = __uint_as_float(sw[1]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -652,7 +668,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD);
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
     { const char *d = getenv("CSK_STAMPS"); p.stamps = d ? (unsigned long long *)strtoull(d, nullptr, 0) : nullptr; }
-    const bool big = (p.Mpad % 128) == 0;
+    const bool big = (p.Mpad % 128) == 0 && !getenv("CSK_TCN_MT64");
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const int max_dt = (NT + V - 2) / V;
     p.ldb = round_up((stride * max_dt + k) * V, 4);
