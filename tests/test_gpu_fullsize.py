@@ -1,0 +1,76 @@
+"""Parity at BASELINE.json's full sizes (configs[1] and configs[2]) on the GPU.
+
+The oracle is too slow for 256 clips / 1024 streams, so it checks a slice, and the rest is covered by a
+size-independent property of the path: every clip / stream is independent of its batch neighbours (eval-mode BN,
+no cross-sample op), hence row i of the full-size result must equal -- bit for bit -- the same clip run
+in a small batch."""
+import pytest
+import torch
+
+import _bootstrap
+from oracle import stgcn_oracle as o
+from tests.helpers import g6_state_dict, max_err
+
+pytestmark = pytest.mark.gpu
+pkg = _bootstrap.load()
+DEV = "cuda:0"
+A = pkg.ntu_graph().A
+TOL = 1e-4
+
+
+def test_config2_batch256_clip_forward():
+    """Full 10-block ST-GCN clip forward, batch 256, NTU-60 shape: logits of an 8-clip slice vs the oracle,
+    and batch invariance over all 256 clips."""
+    a, sd, _ = g6_state_dict("ntu")
+    net = pkg.StGcn(A).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    x = torch.rand((256, 3, 300, 25, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    full = net(x)
+    assert full.shape == (256, 60) and bool(torch.isfinite(full).all())
+    idx = [0, 1, 37, 100, 128, 200, 254, 255]
+    with torch.no_grad():
+        want = o.stgcn_forward(x[idx].cpu(), sd)
+    assert max_err(full[idx].cpu(), want) <= TOL
+    for lo in range(0, 256, 64):                                  # batch invariance, bitwise
+        part = net(x[lo:lo + 64].contiguous())
+        assert torch.equal(part, full[lo:lo + 64])
+
+
+def test_config3_1024_streams_online():
+    """CoST-GCN online inference with 1024 concurrent streams: predictions of 2 streams vs the oracle stepping
+    those streams alone; stream invariance (bitwise) between the 1024-stream slab and a 4-stream slab; and
+    the 4-frame cycle launches vs per-frame stepping."""
+    a, sd, _ = g6_state_dict("ntu")
+    T = 76 + 4 * 4 + 1
+    g = torch.Generator(device=DEV).manual_seed(2)
+    frames = torch.rand((T, 1024, 3, 25, 2), device=DEV, generator=g)
+    big = pkg.CoStGcn(A, pool_size=3, pool_padding=1).eval()
+    big.load_state_dict(sd, strict=True)
+    big = big.to(DEV)
+    got = []
+    t = 0
+    while t < T:
+        r = min(4, T - t)
+        got += big.forward_cycle([frames[t + f] for f in range(r)])
+        t += r
+    assert len(got) >= 3 and all(gv.shape == (1024, 60) for gv in got)
+    pick = [5, 1000]
+    orc = o.CoStGcnOracle(sd, pool_size=3, pool_padding=1)
+    want = []
+    with torch.no_grad():
+        for t in range(T):
+            r = orc.forward_step(frames[t][pick].cpu())
+            if r is not None:
+                want.append(r)
+    assert len(want) == len(got)
+    for gv, wv in zip(got, want):
+        assert max_err(gv[pick].cpu(), wv) <= TOL
+    small = pkg.CoStGcn(A, pool_size=3, pool_padding=1).eval()
+    small.load_state_dict(sd, strict=True)
+    small = small.to(DEV)
+    sel = [5, 6, 999, 1000]
+    got_small = [r for r in (small.forward_step(frames[t][sel].contiguous()) for t in range(T)) if r is not None]
+    for gv, sv in zip(got, got_small):
+        assert torch.equal(gv[sel], sv)
+    assert abs(big.state_bytes() / 1e9 - 4.0) < 3.0
