@@ -19,6 +19,7 @@ residual FIFO (``co.Delay``) costs no copy.  ``engine_advance`` consumes up to 4
 stride cycle of the 10-block stack) with one GCN launch and one multi-emission TCN launch per block,
 which is what fills the GPU at ~1000 streams; per-frame stepping is the same code with r = 1.
 """
+import ctypes
 import math
 from collections import OrderedDict
 from typing import Optional
@@ -299,6 +300,8 @@ class CoStGcn(_Folded):
     (what ``map_state_dict`` does in the reference, base.py:200-224).
     """
 
+    use_native_plan = True      # False: drive every launch from Python (same kernels, same results)
+
     def __init__(self, graph_A, input_shape=(3, 300, 25, 2), num_classes=60, pool_size=-1, pool_padding=-1,
                  CoGraphConv=CoGraphConvolution):
         super().__init__()
@@ -351,6 +354,76 @@ class CoStGcn(_Folded):
         self._pool_ring = torch.zeros((self.pool_size, n, 256), device=device, dtype=torch.float32)
         self._pooled = torch.empty((n, 256), device=device, dtype=torch.float32)
         self._frames = self._feats = 0
+        self._build_plan(device)
+
+    # ---- native executor ---------------------------------------------------------------------------
+    def _weights_version(self):
+        return tuple(t._version for t in self._all_tensors)
+
+    def _layer_structs(self, device):
+        """(ctypes array of csk_co_layer, objects to keep alive) from the blocks' packed operands and state."""
+        arr, keep = (native.CoLayer * 10)(), []
+        for i in range(10):
+            blk = self.layers[f"layer{i + 1}"]
+            g, t, st = blk.gcn._packed_ops(device), blk._packed_ops(device), blk._state
+            keep += [g, t]
+            L = arr[i]
+            L.c_in, L.c_out, L.stride = blk.in_channels, blk.out_channels, blk.stride
+            L.res_kind = {"none": 0, "identity": 1, "conv": 2}[blk.kind]
+            L.gcn_res_mode, L.ell_w = g["res_mode"], g["ell_w"]
+            for j in range(3):
+                L.ell_cnt[j] = int(g["ell_cnt_host"][j])
+            L.gcn_w, L.gcn_bias = g["w"].data_ptr(), g["bias"].data_ptr()
+            L.ell_src, L.ell_val = g["ell_src"].data_ptr(), g["ell_val"].data_ptr()
+            L.tcn_w, L.tcn_bias = t["w"].data_ptr(), t["bias"].data_ptr()
+            L.tcn_w_res = t["w_res"].data_ptr() if t["w_res"] is not None else None
+            L.y_ring, L.out_ring = st.y.data_ptr(), st.out.data_ptr()
+        ops = self._packed_ops(device)
+        fcw, fcb = self.fc.weight.detach(), self.fc.bias.detach()
+        keep += [ops, fcw, fcb]
+        return arr, keep, ops, fcw, fcb
+
+    def _build_plan(self, device):
+        """csk_co_plan (include/cskel.h): one C call per cycle instead of ~25 ctypes calls.  Built for stacks of
+        plain GraphConvolution blocks; other graph convs (A-GCN) keep the Python engine below."""
+        self._destroy_plan()
+        self._all_tensors = list(self.parameters()) + list(self.buffers())
+        if not self.use_native_plan:
+            return
+        if not all(type(self.layers[f"layer{i + 1}"].gcn) is GraphConvolution for i in range(10)):
+            return
+        c, _, v, m = self.input_shape
+        arr, keep, ops, fcw, fcb = self._layer_structs(device)
+        plan = native.lib().csk_co_plan_create(10, ctypes.byref(arr), native.ptr(self._xin0), self._n, c, v, m, self._p,
+                                               native.ptr(ops["scale"]), native.ptr(ops["shift"]), self.num_classes,
+                                               native.ptr(fcw), native.ptr(fcb), self.pool_size, self.pool_padding,
+                                               native.ptr(self._pool_ring), native.ptr(self._pooled))
+        if not plan:
+            raise RuntimeError("csk_co_plan_create: " + native.lib().csk_last_error().decode())
+        self.__dict__["_plan"] = plan
+        self.__dict__["_plan_keep"] = (keep, self._weights_version())
+
+    def _refresh_plan_weights(self, device):
+        """Weights were reloaded / edited in place: refold and hand the new operands to the plan; the
+        continual state and its counters are untouched (same semantics as the reference, where weights and
+        state buffers are independent)."""
+        arr, keep, ops, fcw, fcb = self._layer_structs(device)
+        rc = native.lib().csk_co_plan_update_weights(self._plan, 10, ctypes.byref(arr), native.ptr(ops["scale"]),
+                                                     native.ptr(ops["shift"]), native.ptr(fcw), native.ptr(fcb))
+        native.check(rc, "csk_co_plan_update_weights")
+        self.__dict__["_plan_keep"] = (keep, self._weights_version())
+
+    def _destroy_plan(self):
+        plan = self.__dict__.pop("_plan", None)
+        if plan:
+            native.lib().csk_co_plan_destroy(plan)
+        self.__dict__.pop("_plan_keep", None)
+
+    def __del__(self):
+        try:
+            self._destroy_plan()
+        except Exception:
+            pass
 
     def state_bytes(self):
         return sum(self.layers[f"layer{i + 1}"]._state.nbytes() for i in range(10)) + 4 * (
@@ -363,22 +436,53 @@ class CoStGcn(_Folded):
                 self.layers[f"layer{i + 1}"].clean_state()
             self._pool_ring.zero_()
             self._frames = self._feats = 0
+            if self.__dict__.get("_plan"):
+                native.lib().csk_co_plan_reset(self._plan)
 
     # ---- stepping ------------------------------------------------------------------------------------
-    def features_cycle(self, frames):
-        """``frames``: sequence of 1..4 tensors (N, C, V, M).  Runs data_bn + the ten blocks for all of them
-        (one GCN + one TCN launch per block).  Returns (first_slot, n_emit) of layer 10's output ring or None."""
+    def _cycle(self, frames):
+        """Advance by 1..4 frames (list of (N, C, V, M) tensors): data_bn, ten blocks, head.
+        Returns (slot, n_feat, logits): layer 10's emissions of this cycle (first output-ring slot, count;
+        (None, 0) if none) and the list of predictions."""
         self._require_eval()
+        frames = list(frames)
+        if not 1 <= len(frames) <= MAX_CYCLE:
+            raise ValueError(f"a cycle holds 1..{MAX_CYCLE} frames, got {len(frames)}")
         x0 = frames[0]
-        native.require_device_f32(x0, "CoStGcn frame")
+        for x_t in frames:
+            native.require_device_f32(x_t, "CoStGcn frame")
+            if x_t.shape != x0.shape or x_t.device != x0.device:
+                raise RuntimeError("all frames of a cycle must have the same shape and device")
         n, c, v, m = x0.shape
         if (c, v, m) != (self.input_shape[0], self.input_shape[2], self.input_shape[3]):
             raise RuntimeError(f"frame shape {tuple(x0.shape)} does not match input_shape {self.input_shape}")
         if self._n != n or self._xin0.device != x0.device:           # clean_state_on_shape_change (base.py:161-164)
             self._bind(n, x0.device)
-        ops = self._packed_ops(x0.device)
+        if self.__dict__.get("_plan"):
+            return self._plan_cycle(frames)
+        return self._python_cycle(frames)
+
+    def _plan_cycle(self, frames):
+        if self._plan_keep[1] != self._weights_version():
+            self._refresh_plan_weights(frames[0].device)
+        n = frames[0].shape[0]
+        ptrs = (ctypes.c_void_p * len(frames))(*[x_t.data_ptr() for x_t in frames])
+        logits = torch.empty((MAX_CYCLE, n, self.num_classes), device=frames[0].device, dtype=torch.float32)
+        slot, nf, nl = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        rc = native.lib().csk_co_plan_cycle(self._plan, ptrs, len(frames), native.ptr(logits), ctypes.byref(slot),
+                                            ctypes.byref(nf), ctypes.byref(nl), native.stream_of(frames[0]))
+        native.check(rc, "csk_co_plan_cycle")
+        self._frames += len(frames)
+        self._feats += nf.value
+        if nf.value == 0:
+            return None, 0, []
+        return slot.value, nf.value, [logits[j] for j in range(nl.value)]
+
+    def _python_cycle(self, frames):
+        """Same protocol driven from Python (any graph-conv module with a ``stage`` method)."""
+        n, c, v, m = frames[0].shape
+        ops = self._packed_ops(frames[0].device)
         for x_t in frames:
-            native.require_device_f32(x_t, "CoStGcn frame")
             dst = self._xin0[self._frames % HIST]
             # reshape1 + data_bn + reshape2 (base.py:73-82) straight into the channel-major input ring
             rc = native.lib().csk_input_norm_f32(native.ptr(x_t), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
@@ -389,14 +493,14 @@ class CoStGcn(_Folded):
         for i in range(10):
             res = self.layers[f"layer{i + 1}"].engine_advance(r, n * m, v)
             if res is None:
-                return None
+                return None, 0, []
             r = res[1]
-        return res
-
-    def features_step(self, x_t):
-        """(N, C, V, M) frame -> slot of layer 10's output ring holding this step's emission, or None."""
-        res = self.features_cycle([x_t])
-        return None if res is None else res[0]
+        outs = []
+        for j in range(res[1]):
+            o = self._head_step((res[0] + j) % HIST, n)
+            if o is not None:
+                outs.append(o)
+        return res[0], res[1], outs
 
     def _head_step(self, slot, n):
         """spatial_pool -> co.AvgPool1d window -> co.Linear (base.py:84-101)."""
@@ -419,23 +523,22 @@ class CoStGcn(_Folded):
                                     stream), "csk_fc_f32")
         return logits
 
+    def features_step(self, x_t):
+        """(N, C, V, M) frame -> slot of layer 10's output ring holding this step's emission, or None
+        (the head advances as well, exactly as in ``forward_step``)."""
+        return self._cycle([x_t])[0]
+
     def forward_step(self, x_t, update_state=True):
+        """CoModelBase.forward_step (base.py:183-185): logits (N, classes) on predicting steps, else None."""
         if not update_state:
             raise NotImplementedError("update_state=False is not supported on the persistent-state path")
-        slot = self.features_step(x_t)
-        return None if slot is None else self._head_step(slot, x_t.shape[0])
+        outs = self._cycle([x_t])[2]
+        return outs[-1] if outs else None
 
     def forward_cycle(self, frames):
         """Up to 4 consecutive frames in one go (list of (N, C, V, M) tensors): same results as calling
         ``forward_step`` on each, with 4x fewer and 4x larger launches.  Returns the list of logits emitted."""
-        res = self.features_cycle(list(frames))
-        outs = []
-        if res is not None:
-            for j in range(res[1]):
-                o = self._head_step((res[0] + j) % HIST, frames[0].shape[0])
-                if o is not None:
-                    outs.append(o)
-        return outs
+        return self._cycle(frames)[2]
 
     def forward_steps(self, x, pad_end=False, update_state=True):
         """(N, C, T, V, M) -> (N, classes, n_predictions) (empty last dim if nothing was emitted)."""

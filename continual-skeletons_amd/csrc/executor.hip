@@ -1,0 +1,157 @@
+// executor.hip -- native step executor for the continual stack (host code only; launches go through the C ABI
+// entry points of stages.hip / step.hip).  Mirrors continual.py:CoSpatioTemporalBlock.engine_advance and
+// CoStGcn.features_cycle / _head_step one to one; the Python versions remain the reference for the protocol.
+#include <vector>
+
+#include "mfma_core.h"
+
+struct BlockCounters {
+    long s = 0;   // frames received
+    long e = 0;   // frames emitted
+};
+
+struct csk_co_plan {
+    std::vector<csk_co_layer> layers;
+    std::vector<BlockCounters> cnt;
+    float *xin0;
+    int N, C, V, M, classes, pool_size, pool_padding;
+    int64_t P;
+    const float *bn_scale, *bn_shift, *fc_w, *fc_b;
+    float *pool_ring, *pooled;
+    long frames = 0, feats = 0;
+};
+
+extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int N, int C, int V,
+                                           int M, int64_t P, const float *bn_scale, const float *bn_shift, int classes,
+                                           const float *fc_w, const float *fc_b, int pool_size, int pool_padding,
+                                           float *pool_ring, float *pooled) {
+    if (n_layers <= 0 || !layers || !xin0 || N <= 0 || C <= 0 || V < 2 || M <= 0 || P < (int64_t)N * M * V || (P & 3) ||
+        !bn_scale || !bn_shift || classes <= 0 || !fc_w || !fc_b || pool_size <= 0 || pool_padding < 0 ||
+        pool_padding >= pool_size || !pool_ring || !pooled) {
+        snprintf(csk_err_buf(), 256, "co_plan_create: bad argument");
+        return nullptr;
+    }
+    for (int i = 0; i < n_layers; ++i) {
+        const csk_co_layer &l = layers[i];
+        if (l.c_in <= 0 || l.c_out <= 0 || l.stride < 1 || l.stride > 2 || !l.gcn_w || !l.gcn_bias || !l.ell_src ||
+            !l.ell_val || !l.tcn_w || !l.tcn_bias || !l.y_ring || !l.out_ring ||
+            (l.res_kind == CSK_RES_CONV && !l.tcn_w_res) || (i > 0 && l.c_in != layers[i - 1].c_out)) {
+            snprintf(csk_err_buf(), 256, "co_plan_create: bad layer %d", i);
+            return nullptr;
+        }
+    }
+    csk_co_plan *p = new csk_co_plan();
+    p->layers.assign(layers, layers + n_layers);
+    p->cnt.resize(n_layers);
+    p->xin0 = xin0; p->N = N; p->C = C; p->V = V; p->M = M; p->P = P;
+    p->bn_scale = bn_scale; p->bn_shift = bn_shift; p->classes = classes; p->fc_w = fc_w; p->fc_b = fc_b;
+    p->pool_size = pool_size; p->pool_padding = pool_padding;
+    p->pool_ring = pool_ring; p->pooled = pooled;
+    return p;
+}
+
+extern "C" void csk_co_plan_destroy(csk_co_plan *plan) { delete plan; }
+
+extern "C" int csk_co_plan_update_weights(csk_co_plan *plan, int n_layers, const csk_co_layer *layers,
+                                          const float *bn_scale, const float *bn_shift, const float *fc_w,
+                                          const float *fc_b) {
+    if (!plan || !layers || !bn_scale || !bn_shift || !fc_w || !fc_b) CSK_FAIL("co_plan_update_weights: null pointer");
+    if (n_layers != (int)plan->layers.size()) CSK_FAIL("co_plan_update_weights: layer count mismatch");
+    for (int i = 0; i < n_layers; ++i) {
+        const csk_co_layer &o = plan->layers[i], &n = layers[i];
+        if (o.c_in != n.c_in || o.c_out != n.c_out || o.stride != n.stride || o.res_kind != n.res_kind ||
+            o.y_ring != n.y_ring || o.out_ring != n.out_ring)
+            CSK_FAIL("co_plan_update_weights: layer %d geometry/state differs", i);
+    }
+    plan->layers.assign(layers, layers + n_layers);
+    plan->bn_scale = bn_scale; plan->bn_shift = bn_shift; plan->fc_w = fc_w; plan->fc_b = fc_b;
+    return 0;
+}
+
+extern "C" void csk_co_plan_reset(csk_co_plan *plan) {
+    if (!plan) return;
+    for (auto &c : plan->cnt) c = BlockCounters();
+    plan->frames = plan->feats = 0;
+}
+
+// one block: r frames are already in xin[(s .. s+r-1) % HIST]; returns emissions via *slot0 / *n_emit
+static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *xin, int r, int n_frames, int V,
+                         int64_t P, int *slot0, int *n_emit, void *stream) {
+    constexpr int K = 9, DELAY = 4, LAG = 4;      // padding="equal": delay = k-1-p = 4; residual lag (k-1)/2
+    const long s0 = c.s;
+    for (int f = 0; f < r;) {                      // per-frame graph conv, one launch per non-wrapping slot run
+        const long s = s0 + f;
+        int run = r - f;
+        if (run > CSK_CO_HIST - (int)(s % CSK_CO_HIST)) run = CSK_CO_HIST - (int)(s % CSK_CO_HIST);
+        if (run > CSK_CO_YRING - (int)(s % CSK_CO_YRING)) run = CSK_CO_YRING - (int)(s % CSK_CO_YRING);
+        const int rc = csk_gcn_stage_f32(xin + (s % CSK_CO_HIST) * (int64_t)l.c_in * P,
+                                         l.y_ring + (s % CSK_CO_YRING) * (int64_t)l.c_out * P, l.gcn_w, l.gcn_bias,
+                                         l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, 0, run, l.c_in, l.c_out, n_frames, V,
+                                         (int64_t)l.c_in * P, P, (int64_t)l.c_out * P, P, l.gcn_res_mode, stream);
+        if (rc) return rc;
+        f += run;
+    }
+    long first = -1;
+    for (long s = s0; s < s0 + r; ++s)
+        if (s >= DELAY && (s - DELAY) % l.stride == 0) { first = s; break; }
+    c.s += r;
+    *n_emit = 0;
+    if (first < 0) return 0;
+    const int ne = (int)((s0 + r - 1 - first) / l.stride) + 1;
+    *slot0 = (int)(c.e % CSK_CO_HIST);
+    const int rc = csk_tcn_step_f32(l.y_ring, CSK_CO_YRING, (int)(first % CSK_CO_YRING), l.stride, ne, l.tcn_w,
+                                    l.res_kind ? xin : nullptr, CSK_CO_HIST, (int)((first - LAG) % CSK_CO_HIST), l.stride,
+                                    l.tcn_w_res, l.tcn_bias, l.out_ring, CSK_CO_HIST, *slot0, l.c_out, l.c_out, P, K,
+                                    l.res_kind, l.res_kind ? l.c_in : 0, 1, stream);
+    if (rc) return rc;
+    c.e += ne;
+    *n_emit = ne;
+    return 0;
+}
+
+extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int r, float *logits, int *last_slot,
+                                 int *n_feat, int *n_logits, void *stream) {
+    if (!p || !frames || !logits || !last_slot || !n_feat || !n_logits) CSK_FAIL("co_plan_cycle: null pointer");
+    if (r < 1 || r > CSK_CO_MAX_CYCLE) CSK_FAIL("co_plan_cycle: r must be in [1, %d]", CSK_CO_MAX_CYCLE);
+    *n_feat = *n_logits = 0;
+    *last_slot = 0;
+    for (int f = 0; f < r; ++f) {                  // reshape1 + data_bn + reshape2 into the channel-major ring
+        if (!frames[f]) CSK_FAIL("co_plan_cycle: null frame");
+        float *dst = p->xin0 + (p->frames % CSK_CO_HIST) * (int64_t)p->C * p->P;
+        const int rc = csk_input_norm_f32(frames[f], p->bn_scale, p->bn_shift, dst, p->N, p->C, 1, p->V, p->M, p->V, p->P,
+                                          stream);
+        if (rc) return rc;
+        p->frames++;
+    }
+    const float *xin = p->xin0;
+    int rr = r, slot0 = 0;
+    for (size_t i = 0; i < p->layers.size(); ++i) {
+        int ne = 0;
+        const int rc = advance_block(p->layers[i], p->cnt[i], xin, rr, p->N * p->M, p->V, p->P, &slot0, &ne, stream);
+        if (rc) return rc;
+        if (ne == 0) return 0;
+        rr = ne;
+        xin = p->layers[i].out_ring;
+    }
+    *last_slot = slot0;
+    *n_feat = rr;
+    const csk_co_layer &last = p->layers.back();
+    const int64_t n_elem = (int64_t)p->N * last.c_out;
+    for (int j = 0; j < rr; ++j) {                 // spatial_pool -> co.AvgPool1d window -> co.Linear
+        const int slot = (slot0 + j) % CSK_CO_HIST;
+        const int head = (int)(p->feats % p->pool_size);
+        int rc = csk_co_spatial_pool_f32(last.out_ring + slot * (int64_t)last.c_out * p->P, p->pool_ring + head * n_elem,
+                                         p->N, last.c_out, p->M * p->V, p->P, stream);
+        if (rc) return rc;
+        p->feats++;
+        if (p->feats < p->pool_size - p->pool_padding) continue;
+        const int count = (int)(p->feats < p->pool_size ? p->feats : p->pool_size);
+        rc = csk_co_window_mean_f32(p->pool_ring, p->pooled, n_elem, p->pool_size, head, count, stream);
+        if (rc) return rc;
+        rc = csk_fc_f32(p->pooled, p->fc_w, p->fc_b, logits + (int64_t)(*n_logits) * p->N * p->classes, p->N,
+                        last.c_out, p->classes, stream);
+        if (rc) return rc;
+        (*n_logits)++;
+    }
+    return 0;
+}

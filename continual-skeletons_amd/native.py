@@ -25,7 +25,24 @@ SIGNATURES = {
     "csk_tcn_step_f32": [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _l, _i, _i, _i, _i, _p],
     "csk_co_spatial_pool_f32": [_p, _p, _i, _i, _i, _l, _p],
     "csk_co_window_mean_f32": [_p, _p, _l, _i, _i, _i, _p],
+
+    "csk_co_plan_create": [_i, _p, _p, _i, _i, _i, _i, _l, _p, _p, _i, _p, _p, _i, _i, _p, _p],
+    "csk_co_plan_destroy": [_p],
+    "csk_co_plan_update_weights": [_p, _i, _p, _p, _p, _p, _p],
+    "csk_co_plan_reset": [_p],
+    "csk_co_plan_cycle": [_p, _p, _i, _p, _p, _p, _p, _p],
 }
+RESTYPES = {"csk_co_plan_create": C.c_void_p, "csk_co_plan_destroy": None, "csk_co_plan_reset": None}
+
+
+class CoLayer(C.Structure):
+    """Mirror of ``csk_co_layer`` (include/cskel.h)."""
+    _fields_ = [("c_in", C.c_int32), ("c_out", C.c_int32), ("stride", C.c_int32), ("res_kind", C.c_int32),
+                ("gcn_res_mode", C.c_int32), ("ell_w", C.c_int32), ("ell_cnt", C.c_int32 * 3), ("pad_", C.c_int32),
+                ("gcn_w", C.c_void_p), ("gcn_bias", C.c_void_p), ("ell_src", C.c_void_p), ("ell_val", C.c_void_p),
+                ("tcn_w", C.c_void_p), ("tcn_w_res", C.c_void_p), ("tcn_bias", C.c_void_p),
+                ("y_ring", C.c_void_p), ("out_ring", C.c_void_p)]
+
 
 _lib = None
 
@@ -42,7 +59,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = args
-            fn.restype = C.c_int
+            fn.restype = RESTYPES.get(name, C.c_int)
         handle.csk_last_error.restype = C.c_char_p
         handle.csk_last_error.argtypes = []
         if handle.csk_abi_version() != ABI_VERSION:

@@ -153,6 +153,48 @@ int csk_co_spatial_pool_f32(const float *h, float *feat, int N, int C, int MV, i
 int csk_co_window_mean_f32(const float *ring, float *pooled, int64_t n_elem, int window, int head, int count,
                            void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native step executor ("plan"): the counterpart of co.Sequential.forward_step driving the ten continual
+ * blocks and the head (models/base.py:108-122,183-190) -- one C call issues every launch of a cycle of 1..4
+ * frames (input norm, per block one GCN-stage + one multi-emission TCN-step launch, spatial pool, temporal
+ * window mean, FC), with the ring-slot / stride-phase bookkeeping kept in the plan.  No allocation, no sync.
+ * ------------------------------------------------------------------------------------------------ */
+#define CSK_CO_HIST 8    /* depth of input / output history rings  */
+#define CSK_CO_YRING 12  /* depth of the post-GCN rings            */
+#define CSK_CO_MAX_CYCLE 4
+
+typedef struct csk_co_layer {
+    int32_t c_in, c_out, stride, res_kind;   /* res_kind: CSK_RES_NONE / IDENTITY / CONV (block residual) */
+    int32_t gcn_res_mode, ell_w, ell_cnt[3];
+    int32_t pad_;
+    const float *gcn_w, *gcn_bias;           /* packed operands of csk_gcn_stage_f32                       */
+    const int32_t *ell_src;
+    const float *ell_val;
+    const float *tcn_w, *tcn_w_res, *tcn_bias; /* packed operands of csk_tcn_step_f32                      */
+    float *y_ring;                           /* [CSK_CO_YRING][c_out][P]                                   */
+    float *out_ring;                         /* [CSK_CO_HIST][c_out][P]; input history of the next layer   */
+} csk_co_layer;
+
+typedef struct csk_co_plan csk_co_plan;
+
+/* xin0: [CSK_CO_HIST][C][P] input ring of layer 0.  pool_ring: [pool_size][N][feat_c]; pooled: [N][feat_c];
+ */
+csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int N, int C, int V, int M,
+                                int64_t P, const float *bn_scale, const float *bn_shift, int classes,
+                                const float *fc_w, const float *fc_b, int pool_size, int pool_padding,
+                                float *pool_ring, float *pooled);
+void csk_co_plan_destroy(csk_co_plan *plan);
+/* swap in refolded weights (same geometry and state rings); counters and state are kept */
+int csk_co_plan_update_weights(csk_co_plan *plan, int n_layers, const csk_co_layer *layers, const float *bn_scale,
+                               const float *bn_shift, const float *fc_w, const float *fc_b);
+/* forget all counters (the caller zeroes the slab): clean_state(), models/base.py:161-164 */
+void csk_co_plan_reset(csk_co_plan *plan);
+/* Advance by r = 1..CSK_CO_MAX_CYCLE frames, frames[i] = (N, C, V, M) device pointers.  On return
+ * *last_slot / *n_feat describe the last layer's emissions of this cycle (slot of the first, count) and
+ * *n_logits how many predictions were written to `logits` ([CSK_CO_MAX_CYCLE][N][classes], slice j = prediction j). */
+int csk_co_plan_cycle(csk_co_plan *plan, const float *const *frames, int r, float *logits, int *last_slot,
+                      int *n_feat, int *n_logits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

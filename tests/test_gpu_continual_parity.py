@@ -165,3 +165,28 @@ def test_forward_cycle_equals_per_frame_stepping():
             t, i = t + r, i + 1
         assert len(got) == len(want) and len(want) >= 8
         assert all(torch.equal(g, w) for g, w in zip(got, want)), pattern
+
+
+def test_native_plan_equals_python_engine_and_survives_weight_reload():
+    """The C++ step executor (csk_co_plan_*) and the Python-driven engine issue the same launches: bitwise equal
+    predictions; reloading weights mid-stream keeps the continual state (as in the reference, where weights and
+    state buffers are independent) on both paths."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:2, :, :140].to(DEV)
+    sd2 = {k: (v * 1.01 if v.dtype.is_floating_point and "running_var" not in k and k.split(".")[-1] != "A" else v)
+           for k, v in sd.items()}
+    outs = {}
+    for native_plan in (True, False):
+        co = pkg.CoStGcn(A, pool_size=4, pool_padding=1).eval()
+        co.use_native_plan = native_plan
+        co.load_state_dict(sd, strict=True)
+        co = co.to(DEV)
+        got = []
+        for t in range(0, 140, 4):
+            if t == 100:
+                co.load_state_dict(sd2, strict=True)
+            got += co.forward_cycle([x[:, :, t + f].contiguous() for f in range(4)])
+        assert (co.__dict__.get("_plan") is not None) == native_plan
+        outs[native_plan] = got
+    assert len(outs[True]) == len(outs[False]) >= 10
+    assert all(torch.equal(p, q) for p, q in zip(outs[True], outs[False]))
