@@ -107,6 +107,9 @@ struct WStage {
             loff[u] = (unsigned)(e * 4);
         }
     }
+    __device__ __forceinline__ void issue_slot(int u, const float *__restrict__ chunk_base) {
+        if (u < WB) v[u] = *reinterpret_cast<const f32x4 *>(chunk_base + goff[u]);
+    }
     // chunk_base = w + c0 * Mpad + m0 (uniform)
     __device__ __forceinline__ void issue(const float *__restrict__ chunk_base) {
 #pragma unroll
@@ -139,6 +142,18 @@ struct BStage {
             valid |= (pp >= 0 && pp < TV) ? (1u << u) : 0u;
         }
     }
+    // slot u of every row this wave owns (used to trickle the loads between MFMA groups)
+    __device__ __forceinline__ void issue_slot(int u, const float *__restrict__ seg_base, int C, int64_t chan_stride,
+                                               int c0, int wave) {
+        if (u >= NJ) return;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int c = c0 + wave + rr * (NTHREADS / 64);
+            const float *src = seg_base + (int64_t)min(c, C - 1) * chan_stride;
+            const float x = src[goff[u]];
+            v[rr][u] = ((c < C ? valid : 0u) >> u) & 1u ? x : 0.f;
+        }
+    }
     // wave is wave-uniform (readfirstlane); rows c0 + wave + 4*rr
     __device__ __forceinline__ void issue(const float *__restrict__ seg_base, int C, int64_t chan_stride, int c0,
                                           int wave) {
@@ -164,3 +179,58 @@ struct BStage {
     }
 };
 
+// Taps [r0, r1) of a chunk (rolled loop; same body as mfma_chunk).  The TCN kernels run a 9-tap chunk as three
+// 3-tap segments with one third of the NEXT chunk's global loads issued in front of each, instead of one burst of
+// 27 loads: measured with in-kernel stamps, the burst cost every wave 2.1-3.7 k cycles per chunk in VMEM-issue
+// stalls (all 8 waves of a CU hit the address unit at once and an in-order wave cannot issue MFMAs meanwhile).
+template <int MT>
+__device__ __forceinline__ void mfma_taps(const float *__restrict__ Wl, const float *__restrict__ Bl, int r0, int r1,
+                                          int ldb, int tapB, int offA, int off0, int off1, int kh,
+                                          f32x16 (&acc)[2][2]) {
+    const float *wr = Wl + r0 * (KC * MT) + offA + kh * MT;
+    const float *br = Bl + r0 * tapB + kh * ldb;
+    float a0 = wr[0], a1 = wr[32], b0 = br[off0], b1 = br[off1];
+    for (int r = r0; r < r1; ++r) {
+        const int rn = min(r + 1, r1 - 1);
+        const float *wn = Wl + rn * (KC * MT) + offA + kh * MT;
+        const float *bn = Bl + rn * tapB + kh * ldb;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            float na0, na1, nb0, nb1;
+            if (s + 1 < KC / 2) {
+                na0 = wr[(2 * s + 2) * MT];
+                na1 = wr[(2 * s + 2) * MT + 32];
+                nb0 = br[(2 * s + 2) * ldb + off0];
+                nb1 = br[(2 * s + 2) * ldb + off1];
+            } else {
+                na0 = wn[0];
+                na1 = wn[32];
+                nb0 = bn[off0];
+                nb1 = bn[off1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        wr = wn;
+        br = bn;
+    }
+}
+
+// one third (slots 3G .. 3G+2, plus 3G+9 .. for long spans) of the next chunk's staging loads; G is a template
+// constant so that every register-array index is a literal when the arrays are scalarised
+template <int G, int MT, int NJ>
+__device__ __forceinline__ void issue_third(WStage<MT> &ws, BStage<NJ> &bs, const float *__restrict__ wnext,
+                                            const float *__restrict__ seg_base, int C, int64_t chan_stride, int cnext,
+                                            int wave) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ws.issue_slot(3 * G + j, wnext);
+        bs.issue_slot(3 * G + j, seg_base, C, chan_stride, cnext, wave);
+        if (NJ > 9) bs.issue_slot(3 * G + j + 9, seg_base, C, chan_stride, cnext, wave);
+    }
+}

@@ -117,15 +117,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         ws.issue(wbase);
         bs.issue(seg_base, p.C, cs, 0, wave);
         int c0 = 0;
+        unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;   // diagnostic phase sums (p.stamps only)
         for (; c0 + KC < p.Cpad; c0 += KC) {
+            if (p.stamps) tq = __builtin_amdgcn_s_memtime();
             __syncthreads();                       // previous chunk's LDS reads are done
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
             ws.commit(Wl);
             bs.commit(Bl, p.ldb, wave);
             __syncthreads();
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
             if (p.stamps && c0 == 0) st1 = __builtin_amdgcn_s_memtime();
-            ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);      // next chunk's loads fly underneath the MFMAs
-            bs.issue(seg_base, p.C, cs, c0 + KC, wave);
-            mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+            {
+                // the next chunk's loads are issued in three bursts of 9 between three tap segments (see mfma_taps)
+                const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
+                const int cn = c0 + KC, t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
+                if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
+                issue_third<0>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
+                issue_third<1>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
+                issue_third<2>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+            }
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph3 += t - tq; tq = t; }
+        }
+        if (p.stamps && lane == 0) {
+            unsigned long long *o = p.stamps + (size_t)gridDim.x * 6 + ((size_t)blockIdx.x * 4 + wave) * 4;
+            o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3;
         }
         __syncthreads();                           // peeled last chunk
         ws.commit(Wl);
@@ -416,10 +434,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
         bgo[u] = (unsigned)(ta * V + j);                   // always inside [0, Q): whole frames of this segment
         blo[u] = (unsigned)j;
     }
-    auto issue = [&](int c0) {
+    auto issue_w = [&](int c0) {
         const float *wc = wbase + (size_t)c0 * p.Mpad;
 #pragma unroll
         for (int u = 0; u < WB; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(wc + wgo[u]);
+    };
+    auto issue_x = [&](int c0) {
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int c = c0 + wave + rr * (NTHREADS / 64);
@@ -442,9 +462,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
 
     const int offA = wm * 64 + l31;
     const int cpad = p.CinPad;                             // multiple of CSK_CPAD == KCG (zero-padded weights)
-    auto mfma_chunk16 = [&]() {
+    auto mfma_steps = [&](int s_begin, int s_end) {
 #pragma unroll 2
-        for (int s = 0; s < KCG / 2; ++s) {
+        for (int s = s_begin; s < s_end; ++s) {
             const int kk = 2 * s + kh;
             const float *bx = Bx + kk * p.ldb;
             float b[R][2];
@@ -471,14 +491,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
             }
         }
     };
-    issue(0);
+    issue_w(0);
+    issue_x(0);
     int c0 = 0;
     for (; c0 + KCG < cpad; c0 += KCG) {
         __syncthreads();
         commit();
         __syncthreads();
-        issue(c0 + KCG);
-        mfma_chunk16();
+        issue_w(c0 + KCG);                                 // next chunk's loads fly underneath the MFMAs
+        issue_x(c0 + KCG);
+        mfma_steps(0, KCG / 2);
     }
     __syncthreads();                                       // peeled last chunk: the staging registers are dead,
     commit();                                              // so the epilogue operands are loaded under its MFMAs
@@ -499,7 +521,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
                 rv[ni][mi][g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
             }
     }
-    mfma_chunk16();
+    mfma_steps(0, KCG / 2);
 
     // epilogue: ReLU(acc + bias + identity residual); permlane32_swap pairs the ni = 0/1 registers so that every
     // store instruction writes one 256-B contiguous row segment (see tcn_stage_kernel)

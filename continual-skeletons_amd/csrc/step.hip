@@ -40,6 +40,17 @@ struct RingStage {
             v[u] = x * (c < C ? 1.f : 0.f);
         }
     }
+    // slots [G*NB/3, (G+1)*NB/3): one third of the chunk (G is a literal so that register indices are static)
+    template <int G>
+    __device__ __forceinline__ void issue_third(const float *const (&base)[9], int taps, int C, int64_t P, int c0) {
+#pragma unroll
+        for (int u = G * (NB / 3); u < (G + 1) * (NB / 3); ++u) {
+            const int tap = min((u * RPU) / KC, taps - 1);
+            const int c = c0 + (u * RPU) % KC + kbase;
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(base[tap] + (int64_t)min(c, C - 1) * P + poff);
+            v[u] = x * (c < C ? 1.f : 0.f);
+        }
+    }
     __device__ __forceinline__ void commit(float *__restrict__ Bl) const {
 #pragma unroll
         for (int u = 0; u < NB; ++u) *reinterpret_cast<f32x4 *>(Bl + (u * RPU + kbase) * NT + poff) = v[u];
@@ -101,17 +112,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
         rs.setup(p0, P, tid);
         ws.issue(wbase);
         rs.issue(slot_base, p.K, p.C, P, 0);
-        for (int c0 = 0; c0 < p.Cpad; c0 += KC) {
+        const int t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
+        int c0 = 0;
+        for (; c0 + KC < p.Cpad; c0 += KC) {
             __syncthreads();
             ws.commit(Wl);
             rs.commit(Bl);
             __syncthreads();
-            if (c0 + KC < p.Cpad) {
-                ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
-                rs.issue(slot_base, p.K, p.C, P, c0 + KC);
-            }
-            mfma_chunk<MT>(Wl, Bl, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
+            // next chunk's loads in three bursts between three tap segments (see mfma_taps in mfma_core.h)
+            const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
+            rs.template issue_third<0>(slot_base, p.K, p.C, P, c0 + KC);
+            mfma_taps<MT>(Wl, Bl, 0, t1, NT, KC * NT, offA, off0, off1, kh, acc);
+#pragma unroll
+            for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
+            rs.template issue_third<1>(slot_base, p.K, p.C, P, c0 + KC);
+            if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NT, KC * NT, offA, off0, off1, kh, acc);
+#pragma unroll
+            for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
+            rs.template issue_third<2>(slot_base, p.K, p.C, P, c0 + KC);
+            if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
         }
+        __syncthreads();
+        ws.commit(Wl);
+        rs.commit(Bl);
+        __syncthreads();
+        mfma_chunk<MT>(Wl, Bl, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
     }
     // ---- phase 2: 1x1 residual conv on the delayed block input (CoTempConv k=1 + co.Delay, base.py:424-441)
     if (p.res_mode == CSK_RES_CONV) {

@@ -16,14 +16,18 @@ for (ci, co, s, res, t) in [(64, 64, 1, True, 300), (256, 256, 1, True, 75)]:
     ops = blk._packed_ops(x.device)
     NT = 128 if co % 128 == 0 else 256
     nwg = ((t * 25 + NT - 1) // NT) * nm * max(1, co // 128 if co % 128 == 0 else co // 64)
-    stamps = torch.zeros(nwg * 6, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(nwg * 6 + nwg * 16, dtype=torch.int64, device=dev)
     for it in range(2):
         os.environ["CSK_STAMPS"] = str(stamps.data_ptr()) if it == 1 else "0"
         if it == 0: os.environ.pop("CSK_STAMPS")
         out = pkg.blocks.tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], 9, s, 4, relu=True, res_mode=1, x_res=x, w_res=None)
         torch.cuda.synchronize()
     os.environ.pop("CSK_STAMPS", None)
-    st = stamps.cpu().numpy().reshape(nwg, 6)
+    allst = stamps.cpu().numpy()
+    st = allst[: nwg * 6].reshape(nwg, 6)
+    ph = allst[nwg * 6:].reshape(nwg, 4, 4)
+    chunks = max(1, co // 8 - 1)
+    print(f"   per-chunk per-wave cycles: barrier1-wait {np.median(ph[:,:,0])/chunks:.0f}  commit+barrier2 {np.median(ph[:,:,1])/chunks:.0f}  issue {np.median(ph[:,:,2])/chunks:.0f}  mfma {np.median(ph[:,:,3])/chunks:.0f}  (ideal mfma alone 9216)")
     pro, loop, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
     tot = st[:, 3] - st[:, 0]
     print(f"C={co}: WGs {nwg}; cycles (s_memtime ticks = 100MHz? check): prologue med {np.median(pro):.0f} p90 {np.percentile(pro,90):.0f} | loop med {np.median(loop):.0f} | epilogue med {np.median(epi):.0f} p90 {np.percentile(epi,90):.0f} | total med {np.median(tot):.0f}")
