@@ -369,7 +369,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
     constexpr int M4 = MT / 4;
     constexpr int WB = R * KCG * M4 / NTHREADS;            // f32x4 of weights per thread per chunk (6 or 8 / 3 or 4)
     constexpr int RPW = KCG / (NTHREADS / 64);             // activation rows per wave per chunk (4)
-    constexpr int NJ = 5;                                  // 64-lane sweeps per activation row (span <= 320)
+    constexpr int NJ = MT == 128 ? 3 : 5;                  // 64-lane sweeps per activation row (span <= 192 / 320)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int V = p.V;
     float *Wl = smem;                                      // [R][KCG][MT]
@@ -656,6 +656,17 @@ __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ feat,
 // C ABI
 // ------------------------------------------------------------------------------------------------
 
+// diagnostics, read from the environment per call only when CSK_DIAG is set at library load (so that the normal
+// launch path never touches the environment): CSK_STAMPS=<device ptr> enables the s_memtime stamps of
+// tcn_stage_kernel (tools/stamp_probe.py), CSK_GCN_GENERAL=1 forces the general (dense-capable) GCN kernel.
+static const bool g_diag = getenv("CSK_DIAG") != nullptr;
+static unsigned long long *diag_stamps() {
+    if (!g_diag) return nullptr;
+    const char *d = getenv("CSK_STAMPS");
+    return d ? (unsigned long long *)strtoull(d, nullptr, 0) : nullptr;
+}
+static bool force_general_gcn() { return g_diag && getenv("CSK_GCN_GENERAL") != nullptr; }
+
 // pick the <MT, NJ> instantiation, raise its dynamic-LDS cap, launch
 template <typename P, typename K>
 static int launch_stage(bool big, bool small_span, dim3 grid, size_t lds, hipStream_t s, const P &p, K k128a, K k128b,
@@ -689,8 +700,8 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.stride = stride; p.pad = pad;
     p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD);
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
-    { const char *d = getenv("CSK_STAMPS"); p.stamps = d ? (unsigned long long *)strtoull(d, nullptr, 0) : nullptr; }
-    const bool big = (p.Mpad % 128) == 0 && !getenv("CSK_TCN_MT64");
+    p.stamps = diag_stamps();
+    const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const int max_dt = (NT + V - 2) / V;
     p.ldb = round_up((stride * max_dt + k) * V, 4);
@@ -740,8 +751,8 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
     dim3 grid(p.qtiles * p.mtiles * n_seg);
     // sparse-graph fast path: shared adjacency with <= 1/1/4 non-zeros per column, activation tile <= 320 positions
-    const bool sparse = adj_seg_stride == 0 && ell_cnt[0] <= 1 && ell_cnt[1] <= 1 && ell_cnt[2] <= 4 && p.ldb <= 320 &&
-                        !getenv("CSK_GCN_GENERAL");
+    const bool sparse = adj_seg_stride == 0 && ell_cnt[0] <= 1 && ell_cnt[1] <= 1 && ell_cnt[2] <= 4 && p.ldb <= (big ? 192 : 320) &&
+                        !force_general_gcn();
     if (sparse) {
         const int R = p.R;
         const size_t lds2 = (size_t)(R * KCG * MT + KCG * p.ldb) * sizeof(float);

@@ -131,3 +131,27 @@ def test_errors_are_loud():
         m(torch.rand(1, 4, 20, 25))
     with pytest.raises(RuntimeError):
         m.to(DEV)(torch.rand(1, 4, 20, 25, device=DEV).double())
+
+
+def test_general_gcn_kernel_matches_sparse_fast_path():
+    """The dense-capable GCN kernel (used for A-GCN / arbitrary adjacencies) and the sparse-graph fast path must
+    agree on a skeleton graph; run the general one in a subprocess (diagnostic switch is read at library load)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); import _bootstrap; pkg = _bootstrap.load();"
+        "torch.manual_seed(3); m = pkg.GraphConvolution(64, 128, pkg.ntu_graph().A).eval();"
+        "[p.data.copy_(torch.rand_like(p) + 0.5) for n, p in m.named_parameters() if n.endswith('graph_attn') or 'bn' in n and n.endswith('weight')];"
+        "x = torch.rand(2, 64, 33, 25); y = m.to('cuda:0')(x.to('cuda:0')).cpu(); torch.save(y, sys.argv[1])"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for general in (False, True):
+        path = f"/tmp/gcn_{int(general)}.pt"
+        env = dict(os.environ)
+        env.pop("CSK_DIAG", None)
+        if general:
+            env.update(CSK_DIAG="1", CSK_GCN_GENERAL="1")
+        subprocess.check_call([sys.executable, "-c", code, path], env=env)
+        outs.append(torch.load(path))
+    assert max_err(outs[0], outs[1]) <= 1e-5

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-workgroup s_memtime stamps of tcn_stage_kernel (prologue / K loop / epilogue split)."""
 import os, sys
+os.environ["CSK_DIAG"] = "1"   # must be set before the library is loaded
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import _bootstrap
