@@ -123,12 +123,13 @@ def step_flops_per_cycle(nm, c_in=3, V=25):
     return 2 * g * nm, 2 * t * nm
 
 
-def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1):
+def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1, native_plan=True):
     """CoST-GCN online inference: `streams` concurrent streams per GPU, persistent ring-buffer state; one
     cycle = 4 consecutive frames (the stack's stride pattern) = one prediction per stream.  With shards > 1 the
     stream axis is split into independent shards advanced on separate HIP streams (parallel.StreamShards)."""
     def make():
         net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+        net.use_native_plan = native_plan     # False: launches are driven from Python so that they can be timed one by one
         randomise_(net, seed=0)
         return net.to(dev)
     eng = parallel.StreamShards(make, streams, shards, dev)
@@ -305,12 +306,10 @@ def main():
     if do_step:
         sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist, args.stream_shards)
         sdt = max_over_ranks(sdt)
-        if args.stream_shards > 1:      # kernel-level timing needs launches that do not overlap: short single-shard pass
-            torch.cuda.empty_cache()
-            _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1)
-            kcycles = 4
-        else:
-            kcycles = args.step_cycles
+        # kernel-level timing: launches must not overlap and must go through the Python hook -> short single-shard pass
+        torch.cuda.empty_cache()
+        _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1, native_plan=False)
+        kcycles = 4
         gfl, tfl = step_flops_per_cycle(args.streams * NTU["M"])
         fps = 4 * args.streams * world * args.step_cycles / sdt
         ach = tfl * kcycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0

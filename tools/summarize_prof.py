@@ -18,8 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rows_of(pattern):
-    files = glob.glob(pattern, recursive=True)
-    return list(csv.DictReader(open(files[0]))) if files else []
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)   # newest run wins
+    return list(csv.DictReader(open(files[-1]))) if files else []
 
 
 def short(name):
