@@ -26,7 +26,7 @@ from .continual import (  # noqa: F401
     CoTemporalConvolution,
 )
 from .agcn import AdaptiveGraphConvolution, AGcn, CoAdaptiveGraphConvolution, CoAGcn  # noqa: F401
-from . import native  # noqa: F401
+from . import fusion, native  # noqa: F401
 
 # names used by BASELINE.json:north_star
 SpatialGraphConv = GraphConvolution
@@ -38,5 +38,5 @@ __all__ = [
     "SpatioTemporalBlock", "SpatialGraphConv", "StGcnBlock", "CoStGcnBlock", "StGcn", "CoStGcn",
     "CoGraphConvolution", "CoTemporalConvolution", "CoSpatioTemporalBlock",
     "AdaptiveGraphConvolution", "CoAdaptiveGraphConvolution", "AGcn", "CoAGcn", "init_weights", "zero", "unity",
-    "native",
+    "native", "fusion",
 ]

@@ -281,3 +281,61 @@ extern "C" int csk_co_window_mean_f32(const float *ring, float *pooled, int64_t 
                        (hipStream_t)stream, ring, pooled, n_elem, window, head, count);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Multi-stream logit fusion + top-k (scripts/multi_stream_eval.py:33-60): fused = left fold of add / maximum over
+// up to 4 prediction arrays (N, classes); rank[n] = number of classes scoring strictly higher than the target
+// class (top-k hit <=> rank < k).  One wave per sample.
+// ------------------------------------------------------------------------------------------------
+struct FuseParams {
+    const float *preds[4];
+    int n_streams, use_max, N, classes;
+    int64_t sample_stride, class_stride;    // element strides of the (N, classes[, steps]) arrays
+};
+
+__global__ __launch_bounds__(256) void fuse_rank_kernel(const FuseParams p, const int64_t *__restrict__ targets,
+                                                        float *__restrict__ fused, int *__restrict__ rank) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    if (n >= p.N) return;
+    const int64_t tgt = targets ? targets[n] : -1;
+    float tv = 0.f;
+    if (tgt >= 0 && tgt < p.classes) {                     // fused score of the target class (same fold order)
+        tv = p.preds[0][n * p.sample_stride + tgt * p.class_stride];
+        for (int s = 1; s < p.n_streams; ++s) {
+            const float v = p.preds[s][n * p.sample_stride + tgt * p.class_stride];
+            tv = p.use_max ? fmaxf(tv, v) : tv + v;
+        }
+    }
+    int higher = 0;
+    for (int c = lane; c < p.classes; c += 64) {
+        float f = p.preds[0][n * p.sample_stride + c * p.class_stride];
+        for (int s = 1; s < p.n_streams; ++s) {
+            const float v = p.preds[s][n * p.sample_stride + c * p.class_stride];
+            f = p.use_max ? fmaxf(f, v) : f + v;
+        }
+        if (fused) fused[n * p.classes + c] = f;
+        higher += (f > tv) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) higher += __shfl_xor(higher, o);
+    if (rank && lane == 0) rank[n] = (tgt >= 0 && tgt < p.classes) ? higher : p.classes;
+}
+
+extern "C" int csk_fuse_rank_f32(const float *const *preds, int n_streams, int use_max, int N, int classes,
+                                 int64_t sample_stride, int64_t class_stride, const int64_t *targets, float *fused,
+                                 int *rank, void *stream) {
+    if (!preds || n_streams < 1 || n_streams > 4) CSK_FAIL("fuse_rank: 1..4 prediction arrays expected");
+    if (N <= 0 || classes <= 0 || (!fused && !rank)) CSK_FAIL("fuse_rank: bad dims / no output requested");
+    if (rank && !targets) CSK_FAIL("fuse_rank: rank requested without targets");
+    FuseParams p;
+    for (int s = 0; s < 4; ++s) {
+        p.preds[s] = s < n_streams ? preds[s] : nullptr;
+        if (s < n_streams && !preds[s]) CSK_FAIL("fuse_rank: null prediction array");
+    }
+    p.n_streams = n_streams; p.use_max = use_max; p.N = N; p.classes = classes;
+    p.sample_stride = sample_stride; p.class_stride = class_stride;
+    hipLaunchKernelGGL(fuse_rank_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, targets,
+                       fused, rank);
+    return (int)hipGetLastError();
+}

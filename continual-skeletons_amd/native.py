@@ -26,6 +26,7 @@ SIGNATURES = {
     "csk_co_spatial_pool_f32": [_p, _p, _i, _i, _i, _l, _p],
     "csk_co_window_mean_f32": [_p, _p, _l, _i, _i, _i, _p],
 
+    "csk_fuse_rank_f32": [_p, _i, _i, _i, _i, _l, _l, _p, _p, _p, _p],
     "csk_co_plan_create": [_i, _p, _p, _i, _i, _i, _i, _l, _p, _p, _i, _p, _p, _i, _i, _p, _p],
     "csk_co_plan_destroy": [_p],
     "csk_co_plan_update_weights": [_p, _i, _p, _p, _p, _p, _p],

@@ -153,6 +153,18 @@ int csk_co_spatial_pool_f32(const float *h, float *feat, int N, int C, int MV, i
 int csk_co_window_mean_f32(const float *ring, float *pooled, int64_t n_elem, int window, int head, int count,
                            void *stream);
 
+/*
+ * Multi-stream logit fusion + top-k support, scripts/multi_stream_eval.py:33-60: fused = left fold of add
+ * (use_max = 0) or maximum (1) over n_streams <= 4 prediction arrays (host array of device pointers); element
+ * (n, c) of every array at n*sample_stride + c*class_stride (a (N, classes, steps) array with the reference's
+ * `preds[:, :, 0]` selection has sample_stride = classes*steps, class_stride = steps).  Outputs (either may be
+ * NULL): fused (N, classes) contiguous; rank[n] = number of classes scoring strictly higher than targets[n]
+ * (top-k hit <=> rank < k; out-of-range targets give rank = classes).
+ */
+int csk_fuse_rank_f32(const float *const *preds, int n_streams, int use_max, int N, int classes,
+                      int64_t sample_stride, int64_t class_stride, const int64_t *targets, float *fused, int *rank,
+                      void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Native step executor ("plan"): the counterpart of co.Sequential.forward_step driving the ten continual
  * blocks and the head (models/base.py:108-122,183-190) -- one C call issues every launch of a cycle of 1..4

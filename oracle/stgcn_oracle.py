@@ -377,3 +377,21 @@ class CoStGcnOracle:
             return None
         pooled = torch.stack(list(self.pool), 0).sum(0) / self.pool_size     # base.py:97
         return F.linear(pooled, self.sd["fc.weight"], self.sd["fc.bias"])   # base.py:99
+
+
+# --------------------------------------------------------------------------------------------
+# Multi-stream fusion + top-k (reference: scripts/multi_stream_eval.py:33-60)
+# --------------------------------------------------------------------------------------------
+def fuse_preds(preds: Sequence[np.ndarray], method=np.add) -> np.ndarray:
+    """``reduce(method, preds[1:], preds[0])`` then ``[:, :, 0]`` for step outputs (multi_stream_eval.py:41,56-57)."""
+    from functools import reduce
+    out = reduce(method, preds[1:], preds[0])
+    return out[:, :, 0] if out.ndim == 3 else out
+
+
+def topk_accuracies_np(preds: np.ndarray, targets: np.ndarray, ks=(1, 3, 5)):
+    """Fraction of samples whose target is among the k best scores (ties: a class only outranks the target when
+    it scores strictly higher)."""
+    tv = preds[np.arange(len(targets)), targets]
+    rank = (preds > tv[:, None]).sum(1)
+    return [float((rank < k).mean()) for k in ks]
