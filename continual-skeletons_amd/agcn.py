@@ -75,8 +75,9 @@ class AdaptiveGraphConvolution(GraphConvolution):
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
         for j in range(n_seg):
-            xf = x.reshape(-1)[j * x_strides[0]:] if n_seg > 1 else x
-            yf = y.reshape(-1)[j * y_strides[0]:] if n_seg > 1 else y
+            # slot j of the ring the views x / y point into (consecutive slots, stride = one frame)
+            xf = torch.as_strided(x, x.shape, x.stride(), x.storage_offset() + j * x_strides[0])
+            yf = torch.as_strided(y, y.shape, y.stride(), y.storage_offset() + j * y_strides[0])
             E = torch.empty((e_ch, p), device=x.device, dtype=torch.float32)
             rc = native.lib().csk_tcn_step_f32(native.ptr(xf), 1, 0, 0, 1, native.ptr(ops["w_embed"]), None, 0, 0, 0, None,
                                                native.ptr(ops["b_embed"]), native.ptr(E), 1, 0, self.in_channels, e_ch, p,

@@ -569,10 +569,9 @@ class CoStGcn(_Folded):
         take = min(tp, self.pool_size - self.pool_padding)
         feat = torch.empty((n, 256), device=x.device, dtype=torch.float32)
         hs = h[:, :, :take].contiguous()
-        rc = native.lib().csk_pool_fc_f32(native.ptr(hs), None, None, native.ptr(feat), None, n, m, 256, take * v, 0,
-                                          native.stream_of(x))
-        native.check(rc, "csk_pool_fc_f32")
-        feat = feat * (take / self.pool_size)
+        rc = native.lib().csk_pool_scaled_f32(native.ptr(hs), native.ptr(feat), n, m, 256, take * v,
+                                              take / self.pool_size, native.stream_of(x))
+        native.check(rc, "csk_pool_scaled_f32")
         logits = torch.empty((n, self.num_classes), device=x.device, dtype=torch.float32)
         native.check(native.lib().csk_fc_f32(native.ptr(feat), native.ptr(self.fc.weight.detach()),
                                              native.ptr(self.fc.bias.detach()), native.ptr(logits), n, 256,

@@ -21,6 +21,10 @@ char *csk_err_buf();   // thread-local message buffer (defined in stages.hip)
     } while (0)
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Raise a kernel's dynamic-LDS cap once (and again only if a larger tile is requested): steady-state launches
+// then consist of hipLaunchKernel alone.  Returns hipSuccess (0) or the error.
+int csk_ensure_lds(const void *kernel, size_t bytes);
 static inline unsigned vmagic_of(int V) { return (unsigned)(((1ull << 32) + V - 1) / V); }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,6 +20,20 @@
 
 #include "mfma_core.h"
 
+#include <mutex>
+#include <unordered_map>
+
+int csk_ensure_lds(const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, size_t> cap;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cap.find(kernel);
+    if (it != cap.end() && it->second >= bytes) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cap[kernel] = bytes;
+    return (int)e;
+}
+
 static thread_local char g_err[256] = "";
 char *csk_err_buf() { return g_err; }
 extern "C" int csk_abi_version(void) { return CSK_ABI_VERSION; }
@@ -622,7 +636,7 @@ __global__ void input_norm_kernel(const float *__restrict__ x, const float *__re
 
 // feat[n, c] = mean over m and over TV positions; one wave per (n, c)
 __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ h, float *__restrict__ feat, int N, int M,
-                                                   int C, int TV) {
+                                                   int C, int TV, float scale) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // (n, c)
     if (row >= (int64_t)N * C) return;
@@ -634,7 +648,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ h, 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) feat[row] = s / (float)((int64_t)M * TV);
+    if (lane == 0) feat[row] = s / (float)((int64_t)M * TV) * scale;
 }
 
 // logits[n, k] = feat[n] . fc_w[k] + fc_b[k]; one wave per output
@@ -672,8 +686,7 @@ template <typename P, typename K>
 static int launch_stage(bool big, bool small_span, dim3 grid, size_t lds, hipStream_t s, const P &p, K k128a, K k128b,
                         K k64a, K k64b) {
     K k = big ? (small_span ? k128a : k128b) : (small_span ? k64a : k64b);
-    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
     hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds, s, p);
     return (int)hipGetLastError();
 }
@@ -758,8 +771,8 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
         const size_t lds2 = (size_t)(R * KCG * MT + KCG * p.ldb) * sizeof(float);
         void (*k)(GcnParams) = big ? (R == 4 ? gcn_stage_sparse_kernel<128, true> : gcn_stage_sparse_kernel<128, false>)
                                    : (R == 4 ? gcn_stage_sparse_kernel<64, true> : gcn_stage_sparse_kernel<64, false>);
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e != hipSuccess) return (int)e;
+        const int e = csk_ensure_lds((const void *)k, lds2);
+        if (e) return e;
         hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds2, (hipStream_t)stream, p);
         return (int)hipGetLastError();
     }
@@ -797,7 +810,7 @@ extern "C" int csk_pool_fc_f32(const float *h, const float *fc_w, const float *f
     if (N <= 0 || M <= 0 || C <= 0 || TV <= 0) CSK_FAIL("pool_fc: bad dims");
     const int64_t rows = (int64_t)N * C;
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, feat, N, M,
-                       C, TV);
+                       C, TV, 1.0f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (logits) return csk_fc_f32(feat, fc_w, fc_b, logits, N, C, classes, stream);
@@ -811,5 +824,14 @@ extern "C" int csk_agcn_attention_f32(const float *E, const float *a_sum, float 
     const size_t lds = (size_t)(2 * 64 * V + V * V) * sizeof(float);
     hipLaunchKernelGGL(agcn_attention_kernel, dim3(n_seg, 3), dim3(256), lds, (hipStream_t)stream, E, a_sum, ell_val,
                        inter, T, V, e_seg_stride, e_chan_stride);
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_pool_scaled_f32(const float *h, float *feat, int N, int M, int C, int TV, float scale, void *stream) {
+    if (!h || !feat) CSK_FAIL("pool_scaled: null pointer");
+    if (N <= 0 || M <= 0 || C <= 0 || TV <= 0) CSK_FAIL("pool_scaled: bad dims");
+    const int64_t rows = (int64_t)N * C;
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, feat, N, M,
+                       C, TV, scale);
     return (int)hipGetLastError();
 }

@@ -250,14 +250,11 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     const size_t lds = (size_t)(9 * KC * MT + 9 * KC * NT) * sizeof(float);   // always 9 taps (73.7 KB)
     dim3 grid((unsigned)((P + NT - 1) / NT), p.Mpad / MT, n_emit);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
     if (big) {
-        e = hipFuncSetAttribute((const void *)tcn_step_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        if (const int e = csk_ensure_lds((const void *)tcn_step_kernel<128>, lds)) return e;
         hipLaunchKernelGGL(tcn_step_kernel<128>, grid, dim3(NTHREADS), lds, s, p);
     } else {
-        e = hipFuncSetAttribute((const void *)tcn_step_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        if (const int e = csk_ensure_lds((const void *)tcn_step_kernel<64>, lds)) return e;
         hipLaunchKernelGGL(tcn_step_kernel<64>, grid, dim3(NTHREADS), lds, s, p);
     }
     return (int)hipGetLastError();

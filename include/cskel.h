@@ -102,6 +102,10 @@ int csk_input_norm_f32(const float *x, const float *scale, const float *shift, f
 int csk_pool_fc_f32(const float *h, const float *fc_w, const float *fc_b, float *feat, float *logits,
                     int N, int M, int C, int TV, int classes, void *stream);
 
+/* feat[n, c] = scale * mean_m mean_{tv} h[n*M+m, c, tv]: the clip-mode evaluation of CoModelBase's head
+ * (spatial_pool + zero-padded co.AvgPool1d window, models/base.py:84-97,166-181) uses scale = frames/pool_size */
+int csk_pool_scaled_f32(const float *h, float *feat, int N, int M, int C, int TV, float scale, void *stream);
+
 /* plain FC on pooled features: logits[n] = feat[n] @ fc_w^T + fc_b  (co.Linear, models/base.py:99) */
 int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *logits,
                int N, int C, int classes, void *stream);

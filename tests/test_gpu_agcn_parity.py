@@ -94,7 +94,14 @@ def test_coagcn_model_steps_vs_oracle():
             r = orc.forward_step(x[:, :, t])
             if r is not None:
                 want.append(r)
-    got = net.to(DEV).forward_steps(x.to(DEV)).cpu()
+    net = net.to(DEV)
+    got = net.forward_steps(x.to(DEV)).cpu()
     want = torch.stack(want, dim=2)
     assert got.shape == want.shape and got.shape[2] >= 2
     assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max()))
+    net.clean_state()                                   # the same frames in 4-frame cycles (multi-slot GCN stage)
+    xd = x.to(DEV)
+    cyc = []
+    for t in range(0, x.shape[2], 4):
+        cyc += net.forward_cycle([xd[:, :, t + f].contiguous() for f in range(4)])
+    assert len(cyc) == got.shape[2] and all(torch.equal(c.cpu(), got[:, :, i]) for i, c in enumerate(cyc))
