@@ -9,13 +9,12 @@ with ``adj_seg_stride`` (aggregation on VALU from LDS-staged tables, channel mix
 Clip mode: one V x V matrix per sample over all T; continual mode (CoAGCN): T = 1, i.e. per-frame attention --
 clip != step by design (a_gcn.py:60-61, coa_gcn.py:31).
 """
-import numpy as np
 import torch
 import torch.nn as nn
 
 from . import blocks, fold, native
-from .blocks import GraphConvolution, SpatioTemporalBlock, _check_input, init_weights
-from .continual import CoSpatioTemporalBlock, CoStGcn
+from .blocks import GraphConvolution, _check_input, init_weights
+from .continual import CoStGcn
 from .models import StGcn
 
 

@@ -28,8 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import blocks, fold, native
-from .blocks import (GraphConvolution, SpatioTemporalBlock, TemporalConvolution, _Folded, gcn_stage,
-                     init_weights, unity, zero)
+from .blocks import GraphConvolution, SpatioTemporalBlock, TemporalConvolution, _Folded, init_weights, unity, zero
 from .models import layer_table
 
 HIST = 8     # depth of an input / output history ring (>= residual lag 4 + the frames of one 4-frame cycle)
