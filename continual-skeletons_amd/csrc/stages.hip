@@ -48,6 +48,7 @@ struct TcnParams {
     int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
     int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
     unsigned vmagic, mtiles, qtiles;
+    int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
 
@@ -147,11 +148,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                 const int cn = c0 + KC, t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
                 if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
                 issue_third<0>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                // raised priority while in an MFMA segment: this wave then wins issue arbitration against the
+                // SIMD partner's commit / load-issue phase (+2 % measured)
+                if (p.prio) __builtin_amdgcn_s_setprio(1);
                 mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
+                __builtin_amdgcn_s_setprio(0);
                 issue_third<1>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                if (p.prio) __builtin_amdgcn_s_setprio(1);
                 if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
+                __builtin_amdgcn_s_setprio(0);
                 issue_third<2>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                if (p.prio) __builtin_amdgcn_s_setprio(1);
                 if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+                __builtin_amdgcn_s_setprio(0);
             }
             if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph3 += t - tq; tq = t; }
         }
@@ -514,7 +523,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
         __syncthreads();
         issue_w(c0 + KCG);                                 // next chunk's loads fly underneath the MFMAs
         issue_x(c0 + KCG);
+        __builtin_amdgcn_s_setprio(1);
         mfma_steps(0, KCG / 2);
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();                                       // peeled last chunk: the staging registers are dead,
     commit();                                              // so the epilogue operands are loaded under its MFMAs
@@ -714,6 +725,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD);
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
     p.stamps = diag_stamps();
+    p.prio = !(g_diag && getenv("CSK_NOPRIO"));
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const int max_dt = (NT + V - 2) / V;

@@ -124,15 +124,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
 #pragma unroll
             for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<0>(slot_base, p.K, p.C, P, c0 + KC);
+            __builtin_amdgcn_s_setprio(1);
             mfma_taps<MT>(Wl, Bl, 0, t1, NT, KC * NT, offA, off0, off1, kh, acc);
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<1>(slot_base, p.K, p.C, P, c0 + KC);
+            __builtin_amdgcn_s_setprio(1);
             if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NT, KC * NT, offA, off0, off1, kh, acc);
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<2>(slot_base, p.K, p.C, P, c0 + KC);
+            __builtin_amdgcn_s_setprio(1);
             if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         ws.commit(Wl);
