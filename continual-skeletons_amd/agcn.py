@@ -68,8 +68,8 @@ class AdaptiveGraphConvolution(GraphConvolution):
 
     def stage(self, x, y, n_seg, frames, x_strides, y_strides):
         """Continual use on channel-major frames (C, P): every skeleton is its own 'sample' with T = 1, so the
-        adjacency is per frame (coa_gcn.py: forward_stepping of the module).  n_seg ring slots are handled one
-        by one."""
+        attention is computed per skeleton (coa_gcn.py: forward_stepping of the module) and the graph conv runs
+        with a per-frame adjacency.  n_seg ring slots are handled one by one."""
         ops = self._packed_ops(x.device)
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
@@ -84,8 +84,9 @@ class AdaptiveGraphConvolution(GraphConvolution):
             native.check(rc, "csk_tcn_step_f32")
             adj = self._attention(E, ops, frames, 1, v, v, p)
             o = dict(ops, ell_val=adj)
-            blocks.gcn_stage(xf, yf, o, n_seg=frames, frames=1, x_strides=(v, p), y_strides=(v, p),
-                             adj_seg_stride=3 * v * v)
+            # one launch over all skeletons: segment = the whole channel-major frame, adjacency per "frame" (skeleton)
+            blocks.gcn_stage(xf, yf, o, n_seg=1, frames=frames, x_strides=(0, p), y_strides=(0, p),
+                             adj_seg_stride=3 * v * v, adj_per_frame=1)
 
 
 def CoAdaptiveGraphConvolution(in_channels, out_channels, A, bn_momentum=0.1):

@@ -122,11 +122,11 @@ class GraphConvolution(_Folded):
         gcn_stage(x, y, self._packed_ops(x.device), n_seg=n_seg, frames=frames, x_strides=x_strides, y_strides=y_strides)
 
 
-def gcn_stage(x, y, ops, n_seg, frames, x_strides, y_strides, adj_seg_stride=0):
+def gcn_stage(x, y, ops, n_seg, frames, x_strides, y_strides, adj_seg_stride=0, adj_per_frame=0):
     rc = native.lib().csk_gcn_stage_f32(
         native.ptr(x), native.ptr(y), native.ptr(ops["w"]), native.ptr(ops["bias"]),
         native.ptr(ops["ell_src"]), native.ptr(ops["ell_val"]), native.ptr(ops["ell_cnt_host"]),
-        ops["ell_w"], adj_seg_stride, n_seg, ops["c_in"], ops["c_out"], frames, ops["V"],
+        ops["ell_w"], adj_seg_stride, adj_per_frame, n_seg, ops["c_in"], ops["c_out"], frames, ops["V"],
         x_strides[0], x_strides[1], y_strides[0], y_strides[1], ops["res_mode"], native.stream_of(x),
     )
     native.check(rc, "csk_gcn_stage_f32")

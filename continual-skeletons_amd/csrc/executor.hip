@@ -86,7 +86,7 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
         if (run > CSK_CO_YRING - (int)(s % CSK_CO_YRING)) run = CSK_CO_YRING - (int)(s % CSK_CO_YRING);
         const int rc = csk_gcn_stage_f32(xin + (s % CSK_CO_HIST) * (int64_t)l.c_in * P,
                                          l.y_ring + (s % CSK_CO_YRING) * (int64_t)l.c_out * P, l.gcn_w, l.gcn_bias,
-                                         l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, 0, run, l.c_in, l.c_out, n_frames, V,
+                                         l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, 0, 0, run, l.c_in, l.c_out, n_frames, V,
                                          (int64_t)l.c_in * P, P, (int64_t)l.c_out * P, P, l.gcn_res_mode, stream);
         if (rc) return rc;
         f += run;

@@ -249,6 +249,9 @@ struct GcnParams {
     int64_t adj_seg_stride, x_seg_stride, x_chan_stride, y_seg_stride, y_chan_stride;
     int Cin, CinPad, Cout, Mpad, frames, V, R, res_mode, ldb;
     unsigned vmagic, mtiles, qtiles;
+    int dense;   // src[e] == e for all subsets and columns (checked on the host side of the ABI by construction)
+    int adj_per_frame;   // the (dense) adjacency varies per FRAME of a segment: index = seg * frames + frame
+    int lds_frames;      // frames of adjacency staged per workgroup in that mode
 };
 
 template <int MT, int NJ>
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
     float *Xa = Wl + R * KC * MT;              // [R][KC][NT]   aggregated operand
     float *Bx = Xa + R * KC * NT;              // [KC][ldb]     raw x frames
     float *Lv = Bx + KC * p.ldb;               // [3][V][EW]    adjacency values
-    int *Ls = reinterpret_cast<int *>(Lv + 3 * V * EW);   // [3][V][EW] adjacency row indices
+    int *Ls = reinterpret_cast<int *>(Lv + 3 * V * EW * (p.adj_per_frame ? p.lds_frames : 1));   // [3][V][EW] row indices
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
@@ -276,16 +279,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
     const int span = (tb - ta + 1) * V;
 
-    // adjacency (fixed graph, or this segment's attention matrix) -> LDS, once per workgroup
+    // adjacency -> LDS, once per workgroup: the fixed graph, this segment's attention matrices, or (per-frame
+    // mode, continual A-GCN where every frame is another skeleton) the matrices of the frames this tile touches
+    const int adj_n = 3 * V * EW;
     {
-        const int n = 3 * V * EW;
-        const float *gv = p.ell_val + (int64_t)seg * p.adj_seg_stride;
-        const int32_t *gs = p.ell_src;             // the index pattern is shared; only the values are per segment
-        for (int e = tid; e < n; e += NTHREADS) {
-            Lv[e] = gv[e];
-            Ls[e] = gs[e];
-        }
+        const int nmat = p.adj_per_frame ? (tb - ta + 1) : 1;
+        const int64_t first = p.adj_per_frame ? ((int64_t)seg * p.frames + ta) : (int64_t)seg;
+        const float *gv = p.ell_val + first * p.adj_seg_stride;
+        const int32_t *gs = p.ell_src;             // the index pattern is shared; only the values vary
+        for (int e = tid; e < adj_n * nmat; e += NTHREADS) Lv[e] = gv[e];
+        for (int e = tid; e < adj_n; e += NTHREADS) Ls[e] = gs[e];
     }
+    // dense mode: every subset lists all V source joints in order (src[e] == e), as the A-GCN host code builds it
+    const bool dense_all = p.dense;
     // aggregation-pass coordinates of this thread: one column, KPT channels
     const int aj = tid % NT, ak0 = (tid / NT) * KPT;
     const int aq = min(q0 + aj, Q - 1);
@@ -321,22 +327,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
             ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
             bs.issue(seg_base, p.Cin, p.x_chan_stride, c0 + KC, wave);
         }
-        // sparse adjacency aggregation: Xa[r][kk][j] = sum_e val * Bx[kk][frame(j) + src]
+        // adjacency aggregation: Xa[r][kk][j] = sum_e val_r[e] * Bx[kk][frame(j) + src_r[e]]
         const float *bx = Bx + ak0 * p.ldb + afb;
-        for (int r = 0; r < 3; ++r) {
-            float s[KPT];
+        if (dense_all) {
+            // dense adjacency (A-GCN): all three subsets share the index pattern src = e, so every x value is
+            // loaded ONCE and feeds the three subsets' accumulators (11 LDS reads per 24 FMAs instead of 30)
+            float s0[KPT], s1[KPT], s2[KPT];
 #pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) s[kk] = 0.f;
-            const int cnt = p.ell_cnt[r];
-            const int eb = (r * V + aw) * EW;
-            for (int e = 0; e < cnt; ++e) {
-                const int src = Ls[eb + e];
-                const float val = Lv[eb + e];
+            for (int kk = 0; kk < KPT; ++kk) s0[kk] = s1[kk] = s2[kk] = 0.f;
+            const int fo = p.adj_per_frame ? (at - ta) * adj_n : 0;          // this column's frame matrix
+            const int eb0 = fo + aw * EW, eb1 = fo + (V + aw) * EW, eb2 = fo + (2 * V + aw) * EW;
+            for (int e = 0; e < V; ++e) {
+                const float v0 = Lv[eb0 + e], v1 = Lv[eb1 + e], v2 = Lv[eb2 + e];
 #pragma unroll
-                for (int kk = 0; kk < KPT; ++kk) s[kk] = fmaf(val, bx[kk * p.ldb + src], s[kk]);
+                for (int kk = 0; kk < KPT; ++kk) {
+                    const float xv = bx[kk * p.ldb + e];
+                    s0[kk] = fmaf(v0, xv, s0[kk]);
+                    s1[kk] = fmaf(v1, xv, s1[kk]);
+                    s2[kk] = fmaf(v2, xv, s2[kk]);
+                }
             }
 #pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) Xa[(r * KC + ak0 + kk) * NT + aj] = s[kk];
+            for (int kk = 0; kk < KPT; ++kk) {
+                Xa[(0 * KC + ak0 + kk) * NT + aj] = s0[kk];
+                Xa[(1 * KC + ak0 + kk) * NT + aj] = s1[kk];
+                Xa[(2 * KC + ak0 + kk) * NT + aj] = s2[kk];
+            }
+        } else {
+            for (int r = 0; r < 3; ++r) {
+                float s[KPT];
+#pragma unroll
+                for (int kk = 0; kk < KPT; ++kk) s[kk] = 0.f;
+                const int cnt = p.ell_cnt[r];
+                const int eb = (r * V + aw) * EW;
+                for (int e = 0; e < cnt; ++e) {
+                    const int src = Ls[eb + e];
+                    const float val = Lv[eb + e];
+#pragma unroll
+                    for (int kk = 0; kk < KPT; ++kk) s[kk] = fmaf(val, bx[kk * p.ldb + src], s[kk]);
+                }
+#pragma unroll
+                for (int kk = 0; kk < KPT; ++kk) Xa[(r * KC + ak0 + kk) * NT + aj] = s[kk];
+            }
         }
         if (R == 4) {   // conv gcn_residual rides the same GEMM as a 4th "subset" with identity adjacency
 #pragma unroll
@@ -578,51 +610,57 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
 __global__ __launch_bounds__(256) void agcn_attention_kernel(const float *__restrict__ E, const float *__restrict__ a_sum,
                                                              float *__restrict__ ell_val, int inter, int T, int V,
                                                              int64_t e_seg_stride, int64_t e_chan_stride) {
-    constexpr int ROWS = 64;                      // (k,t) rows per LDS pass
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ea = smem;                             // [ROWS][V]
-    float *Eb = smem + ROWS * V;                  // [ROWS][V]
-    float *L = smem + 2 * ROWS * V;               // [V][V] logits
-    const int n = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
-    const int VV = V * V, K = inter * T;
-    const float *ea = E + (int64_t)n * e_seg_stride + (int64_t)i * inter * e_chan_stride;       // row (k,t) at k*chan + t*V
+    // logits = Ea^T . Eb over K = inter*T rows as an fp32-MFMA product: A[i = v][k] = Ea[row k][v],
+    // B[k][j = w] = Eb[row k][w] (V <= 32 columns used), operands straight from global memory (each row is V
+    // contiguous floats).  The four waves take interleaved k-steps (2 rows each) and their partial 32x32 tiles
+    // are summed through LDS.
+    __shared__ float part[4][32][33];
+    const int n = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int K = inter * T;
+    const float *ea = E + (int64_t)n * e_seg_stride + (int64_t)i * inter * e_chan_stride;
     const float *eb = E + (int64_t)n * e_seg_stride + (int64_t)(3 + i) * inter * e_chan_stride;
-    const int TV = T * V;
-    float acc[3] = {0.f, 0.f, 0.f};
-    int pv[3], pw[3];
+    f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int pidx = min(tid + j * 256, VV - 1);
-        pv[j] = pidx / V;
-        pw[j] = pidx % V;
-    }
-    for (int r0 = 0; r0 < K; r0 += ROWS) {
-        const int nr = min(ROWS, K - r0);
-        __syncthreads();
-        for (int e = tid; e < nr * V; e += 256) {
-            const int g = r0 * V + e;                                  // flat (k, t, v) index; k = g / (T*V)
-            const int64_t off = (int64_t)(g / TV) * e_chan_stride + (g % TV);
-            Ea[e] = ea[off];
-            Eb[e] = eb[off];
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    // this lane's row index g = 2 * (4 s + wave) + kh, tracked as (channel kc, time t) without divisions
+    int g = 2 * wave + kh;
+    int kc = g / T, t = g - kc * T;
+    const bool col = l31 < V;
+    constexpr int UN = 4;
+    for (; g < K + 8 * UN; g += 8 * UN) {
+        float av[UN], bv[UN];
+        int gg = g, kk = kc, tt = t;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool ok = col && gg < K;
+            const int64_t off = (int64_t)min(kk, inter - 1) * e_chan_stride + (int64_t)tt * V + min(l31, V - 1);
+            const float xa = ea[off], xb = eb[off];
+            av[u] = ok ? xa : 0.f;
+            bv[u] = ok ? xb : 0.f;
+            gg += 8; tt += 8;
+            while (tt >= T) { tt -= T; ++kk; }
         }
-        __syncthreads();
-        for (int r = 0; r < nr; ++r) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] = fmaf(Ea[r * V + pv[j]], Eb[r * V + pw[j]], acc[j]);
-        }
+        for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        kc = kk; t = tt;
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (tid + j * 256 < VV) L[tid + j * 256] = acc[j] / (float)K;
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * kh][l31] = acc[r];   // [v][w]
     __syncthreads();
-    if (tid < V) {                                // softmax over v for column w = tid
+    if (tid < V) {                                // softmax over v (dim -2) for column w = tid
         const int w = tid;
+        float lg[32];
         float m = -INFINITY;
-        for (int v = 0; v < V; ++v) m = fmaxf(m, L[v * V + w]);
+        for (int v = 0; v < V; ++v) {
+            lg[v] = (part[0][v][w] + part[1][v][w] + part[2][v][w] + part[3][v][w]) / (float)K;
+            m = fmaxf(m, lg[v]);
+        }
         float sum = 0.f;
-        for (int v = 0; v < V; ++v) sum += expf(L[v * V + w] - m);
+        for (int v = 0; v < V; ++v) sum += expf(lg[v] - m);
         float *dst = ell_val + ((int64_t)(n * 3 + i) * V + w) * V;
-        for (int v = 0; v < V; ++v) dst[v] = expf(L[v * V + w] - m) / sum + a_sum[(i * V + v) * V + w];
+        for (int v = 0; v < V; ++v) dst[v] = expf(lg[v] - m) / sum + a_sum[(i * V + v) * V + w];
     }
 }
 
@@ -744,6 +782,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
 
 extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
                                  const float *ell_val, const int32_t *ell_cnt, int ell_w, int64_t adj_seg_stride,
+                                 int adj_per_frame,
                                  int n_seg, int c_in, int c_out, int frames, int V, int64_t x_seg_stride,
                                  int64_t x_chan_stride, int64_t y_seg_stride, int64_t y_chan_stride, int res_mode,
                                  void *stream) {
@@ -763,12 +802,17 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     p.y_seg_stride = y_seg_stride; p.y_chan_stride = y_chan_stride;
     p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.frames = frames; p.V = V; p.R = res_mode == CSK_RES_CONV ? 4 : 3; p.res_mode = res_mode;
+    // per-segment adjacencies are dense by contract (include/cskel.h): ell_w == V, ell_cnt == {V,V,V}, src[e] == e
+    p.dense = adj_seg_stride != 0 && ell_w == V && ell_cnt[0] == V && ell_cnt[1] == V && ell_cnt[2] == V;
+    p.adj_per_frame = adj_per_frame != 0;
+    if (p.adj_per_frame && !p.dense) CSK_FAIL("gcn_stage: per-frame adjacency must be dense (ell_w == V, ell_cnt == V)");
     p.vmagic = vmagic_of(V);
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const int max_dt = (NT + V - 2) / V;
     p.ldb = round_up((max_dt + 1) * V, 4);
-    const size_t lds = (size_t)(p.R * KC * MT + p.R * KC * NT + KC * p.ldb + 2 * 3 * V * ell_w) * sizeof(float);
+    p.lds_frames = max_dt + 1;
+    const size_t lds = (size_t)(p.R * KC * MT + p.R * KC * NT + KC * p.ldb + 3 * V * ell_w * (1 + (p.adj_per_frame ? p.lds_frames : 1))) * sizeof(float);
     if (lds > 160 * 1024) CSK_FAIL("gcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = frames * V;
     if ((int64_t)frames * V >= (1 << 26)) CSK_FAIL("gcn_stage: frames*V too large for 32-bit position arithmetic");
@@ -832,9 +876,8 @@ extern "C" int csk_pool_fc_f32(const float *h, const float *fc_w, const float *f
 extern "C" int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, int n_seg, int inter, int T,
                                       int V, int64_t e_seg_stride, int64_t e_chan_stride, void *stream) {
     if (!E || !a_sum || !ell_val) CSK_FAIL("agcn_attention: null pointer");
-    if (n_seg <= 0 || inter <= 0 || T <= 0 || V < 2 || V > 27) CSK_FAIL("agcn_attention: bad dims (V <= 27)");
-    const size_t lds = (size_t)(2 * 64 * V + V * V) * sizeof(float);
-    hipLaunchKernelGGL(agcn_attention_kernel, dim3(n_seg, 3), dim3(256), lds, (hipStream_t)stream, E, a_sum, ell_val,
+    if (n_seg <= 0 || inter <= 0 || T <= 0 || V < 2 || V > 32) CSK_FAIL("agcn_attention: bad dims (V <= 32)");
+    hipLaunchKernelGGL(agcn_attention_kernel, dim3(n_seg, 3), dim3(256), 0, (hipStream_t)stream, E, a_sum, ell_val,
                        inter, T, V, e_seg_stride, e_chan_stride);
     return (int)hipGetLastError();
 }

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 2
+#define CSK_ABI_VERSION 3
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -52,12 +52,17 @@ const char *csk_last_error(void);
  *  ell_val  [3][V][ell_w] fp32  : their values (padded with 0.0)
  *  ell_cnt  [3] : number of meaningful entries per subset (<= ell_w) -- lets sparse subsets skip padding
  *  adj_seg_stride: 0 for a graph shared by all segments (ST-GCN); 3*V*ell_w for per-segment VALUES
- *           (A-GCN's per-sample attention, models/a_gcn/a_gcn.py:62-65; ell_src stays shared).
+ *           (A-GCN's per-sample attention, models/a_gcn/a_gcn.py:62-65; ell_src stays shared).  A per-segment
+ *           adjacency with ell_w == V and ell_cnt == {V,V,V} MUST list every source joint in order
+ *           (ell_src[i][w][e] == e): the kernel then takes its dense fast path and does not read ell_src.
+ *  adj_per_frame: 0, or 1 = the dense adjacency varies per FRAME: matrix index = seg*frames + frame, consecutive
+ *           matrices adj_seg_stride apart (continual A-GCN: every frame of the channel-major layout is another
+ *           skeleton with its own attention, models/coa_gcn/coa_gcn.py:11-14).
  *  res_mode CSK_RES_IDENTITY (c_in == c_out) or CSK_RES_CONV.
  */
 int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias,
                       const int32_t *ell_src, const float *ell_val, const int32_t *ell_cnt,
-                      int ell_w, int64_t adj_seg_stride,
+                      int ell_w, int64_t adj_seg_stride, int adj_per_frame,
                       int n_seg, int c_in, int c_out, int frames, int V,
                       int64_t x_seg_stride, int64_t x_chan_stride,
                       int64_t y_seg_stride, int64_t y_chan_stride,
