@@ -1,5 +1,5 @@
 // executor.hip -- native step executor for the continual stack (host code only; launches go through the C ABI
-// entry points of stages.hip / step.hip).  Mirrors continual.py:CoSpatioTemporalBlock.engine_advance and
+// entry points of gcn.hip / step.hip / head.hip).  Mirrors continual.py:CoSpatioTemporalBlock.engine_advance and
 // CoStGcn.features_cycle / _head_step one to one; the Python versions remain the reference for the protocol.
 #include <vector>
 

@@ -1,4 +1,4 @@
-// mfma_core.h -- device-side building blocks shared by the clip (stages.hip) and continual (step.hip) kernels:
+// mfma_core.h -- device-side building blocks shared by the clip (tcn.hip, gcn.hip) and continual (step.hip) kernels:
 // the fp32-MFMA "shifted GEMM" chunk, and the issue/commit staging helpers (register prefetch).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: sta
 static constexpr int KC = CSK_KC;
 static constexpr int NTHREADS = 256;
 
-char *csk_err_buf();   // thread-local message buffer (defined in stages.hip)
+char *csk_err_buf();   // thread-local message buffer (defined in runtime.hip)
 #define CSK_FAIL(...)                                   \
     do {                                                \
         snprintf(csk_err_buf(), 256, __VA_ARGS__);      \
@@ -25,6 +25,9 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // Raise a kernel's dynamic-LDS cap once (and again only if a larger tile is requested): steady-state launches
 // then consist of hipLaunchKernel alone.  Returns hipSuccess (0) or the error.
 int csk_ensure_lds(const void *kernel, size_t bytes);
+// diagnostic switches (runtime.hip): active only when CSK_DIAG was set when the library was loaded
+bool csk_diag_flag(const char *name);
+unsigned long long *csk_diag_stamps();
 static inline unsigned vmagic_of(int V) { return (unsigned)(((1ull << 32) + V - 1) / V); }
 
 // ------------------------------------------------------------------------------------------------

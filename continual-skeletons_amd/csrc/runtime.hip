@@ -1,0 +1,46 @@
+// runtime.hip -- library glue of libcskel_hip.so: error text, ABI version, diagnostic switches, LDS-attribute cache.
+//
+// Overview of csrc/ (all compiled into libcskel_hip.so by build.sh, C ABI in include/cskel.h):
+//   mfma_core.h   shared device code: fp32-MFMA "shifted GEMM" chunk, issue/commit staging (register prefetch)
+//   runtime.hip   library glue: error text, ABI version, diagnostics switches, LDS-attribute cache
+//   tcn.hip       tcn_stage_kernel      + csk_tcn_stage_f32        (clip TCN stage)
+//   gcn.hip       gcn_stage_* kernels   + csk_gcn_stage_f32        (GCN stage: sparse fast path + general)
+//   agcn.hip      agcn_attention_kernel + csk_agcn_attention_f32   (A-GCN per-sample adjacency)
+//   head.hip      input norm / pooling / FC kernels and entry points
+//   step.hip      continual path: tcn_step_kernel, spatial pool, window mean, logit fusion
+//   executor.hip  native step executor (csk_co_plan_*)
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <unordered_map>
+
+#include "mfma_core.h"
+
+int csk_ensure_lds(const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, size_t> cap;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cap.find(kernel);
+    if (it != cap.end() && it->second >= bytes) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cap[kernel] = bytes;
+    return (int)e;
+}
+
+static thread_local char g_err[256] = "";
+char *csk_err_buf() { return g_err; }
+extern "C" int csk_abi_version(void) { return CSK_ABI_VERSION; }
+extern "C" const char *csk_last_error(void) { return g_err; }
+
+// Diagnostics are read from the environment per call only when CSK_DIAG is set at library load (so that the normal
+// launch path never touches the environment): CSK_STAMPS=<device ptr> enables the s_memtime stamps of
+// tcn_stage_kernel (tools/stamp_probe.py), CSK_GCN_GENERAL=1 forces the general (dense-capable) GCN kernel,
+// CSK_NOPRIO=1 drops the raised wave priority inside MFMA segments (tools/ab_probe.py).
+static const bool g_diag = getenv("CSK_DIAG") != nullptr;
+bool csk_diag_flag(const char *name) { return g_diag && getenv(name) != nullptr; }
+unsigned long long *csk_diag_stamps() {
+    if (!g_diag) return nullptr;
+    const char *d = getenv("CSK_STAMPS");
+    return d ? (unsigned long long *)strtoull(d, nullptr, 0) : nullptr;
+}

@@ -5,7 +5,7 @@
 // with the joint innermost.  Per block:
 //     y ring   [9][C_out][P]   post-GCN frames  (the (k-1)-frame window of co.Conv2d + the new frame)
 //     out ring [5][C_out][P]   block outputs    (doubles as the next block's residual FIFO, co.Delay(4))
-// A step of a block = gcn_stage on the new frame (stages.hip, frames == skeletons) writing ring slot s % 9,
+// A step of a block = gcn_stage on the new frame (gcn.hip, frames == skeletons) writing ring slot s % 9,
 // then -- on emitting steps -- tcn_step below: the 9 taps of the temporal conv are the 9 ring slots at the
 // SAME positions, so the GEMM is  D[co, p] = sum_r sum_c W[r][c][co] * ring[(head - 8 + r) % 9][c][p].
 // Zero-initialised slots reproduce the zero left-padding of the clip conv (models/base.py:307-334 semantics).

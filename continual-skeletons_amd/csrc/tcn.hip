@@ -1,0 +1,269 @@
+// tcn.hip -- TCN stage of the ST-GCN clip forward path (gfx950 / MI355X).  The GCN stage is in gcn.hip.
+//
+// Two stage kernels per SpatioTemporalBlock, both built on one fp32-MFMA "shifted GEMM" core:
+//
+//   gcn_stage : y   = ReLU( W' . agg(x) + b' + gcn_residual(x) )          models/base.py:260-270
+//   tcn_stage : out = ReLU( W' . taps(y) + b' + block_residual(x) )        models/base.py:302-304,376-387
+//
+// GEMM view (per skeleton sequence = "segment"):  D[co, q] = sum_r sum_c W[r][c][co] * B_r[c][q]
+//   q  = flattened (frame, joint) position, V innermost  -> coalesced HBM rows, conflict-free LDS reads
+//   TCN: B_r[c][q] = y[c][q + (r - pad) * V]      -- a tap is an address shift inside one LDS tile
+//   GCN: B_r[c][q] = sum_v x[c][frame(q), v] * A_eff[r][v, joint(q)]   -- sparse (ELL) VALU gather
+//        into an LDS tile, adjacency tables staged in LDS
+// Arithmetic: exact fp32 (v_mfma_f32_32x32x2_f32), BatchNorm(eval)/biases folded into W'/b' on the host.
+//
+// Tiling: 256 threads = 4 waves, each wave owns a 64x64 output tile (2x2 MFMA 32x32 accumulators);
+// workgroup tile MT x NT with MT*NT = 16384 (64x256 for C_out = 64, 128x128 otherwise).  K loop walks
+// channel chunks of KC = 8; one activation chunk in LDS serves all 9 taps.
+#include "mfma_core.h"
+
+// ------------------------------------------------------------------------------------------------
+// TCN stage
+// ------------------------------------------------------------------------------------------------
+struct TcnParams {
+    const float *y, *w, *xres, *wres, *bias;
+    float *out;
+    int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
+    int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
+    unsigned vmagic, mtiles, qtiles;
+    int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
+    unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
+};
+
+template <int MT, int NJ>
+__global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams p) {
+    constexpr int NT = 16384 / MT;
+    constexpr int WM = MT / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem;
+    float *Bl = smem + p.K * KC * MT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    // work item -> (m-tile fastest: shares the activation tile; then position tile: shares halos; then segment)
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
+    const int seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int V = p.V, Q = p.Tout * V;
+    const int qend = min(q0 + NT, Q);
+    const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
+
+    int off[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+        const int t = div_magic(q, p.vmagic);
+        off[ni] = p.stride * (t - ta) * V + (q - t * V);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const int offA = wm * 64 + l31;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
+    WStage<MT> ws;
+    BStage<NJ> bs;
+    // epilogue operands: 32 biases + (identity residual) 64 block-input values per lane.  They are loaded
+    // UNDER THE LAST CHUNK'S MFMAs (the K loops are peeled by one iteration; the staging registers are dead
+    // there), unconditionally (clamped indices, bias padded to Mpad), so the epilogue itself is stores only.
+    float *oseg = p.out + (int64_t)seg * p.Cout * Q;
+    const float *rseg = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+    const int64_t rcs = (int64_t)p.Tres * V;
+    const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    float bv[2][16], rv[2][2][16];
+    auto issue_epilogue_loads = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+            const int t = div_magic(qc, p.vmagic);
+            const int qres = ident ? (t * p.stride + p.res_off) * V + (qc - t * V) : 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int co = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    rv[ni][mi][g] = ident ? rseg[(int64_t)min(co, p.Cout - 1) * rcs + qres] : 0.f;
+                }
+        }
+    };
+    const bool conv_res = p.res_mode == CSK_RES_CONV;
+    // ---- phase 1: k x 1 temporal conv over y
+    {
+        const int fa = p.stride * ta - p.pad;
+        const int span = (p.stride * (tb - ta) + p.K) * V;
+        const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V;
+        const int64_t cs = (int64_t)p.Tin * V;
+        const float *wbase = p.w + m0;
+        ws.setup(p.K, p.Cpad, p.Mpad, tid);
+        bs.setup(fa * V, span, p.Tin * V, lane);
+        ws.issue(wbase);
+        bs.issue(seg_base, p.C, cs, 0, wave);
+        int c0 = 0;
+        unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;   // diagnostic phase sums (p.stamps only)
+        for (; c0 + KC < p.Cpad; c0 += KC) {
+            if (p.stamps) tq = __builtin_amdgcn_s_memtime();
+            __syncthreads();                       // previous chunk's LDS reads are done
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
+            ws.commit(Wl);
+            bs.commit(Bl, p.ldb, wave);
+            __syncthreads();
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
+            if (p.stamps && c0 == 0) st1 = __builtin_amdgcn_s_memtime();
+            {
+                // the next chunk's loads are issued in three bursts of 9 between three tap segments (see mfma_taps)
+                const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
+                const int cn = c0 + KC, t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
+                if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
+                issue_third<0>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                // raised priority while in an MFMA segment: this wave then wins issue arbitration against the
+                // SIMD partner's commit / load-issue phase (+2 % measured)
+                if (p.prio) __builtin_amdgcn_s_setprio(1);
+                mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
+                __builtin_amdgcn_s_setprio(0);
+                issue_third<1>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                if (p.prio) __builtin_amdgcn_s_setprio(1);
+                if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
+                __builtin_amdgcn_s_setprio(0);
+                issue_third<2>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
+                if (p.prio) __builtin_amdgcn_s_setprio(1);
+                if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph3 += t - tq; tq = t; }
+        }
+        if (p.stamps && lane == 0) {
+            unsigned long long *o = p.stamps + (size_t)gridDim.x * 6 + ((size_t)blockIdx.x * 4 + wave) * 4;
+            o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3;
+        }
+        __syncthreads();                           // peeled last chunk
+        ws.commit(Wl);
+        bs.commit(Bl, p.ldb, wave);
+        __syncthreads();
+        if (!conv_res) issue_epilogue_loads();
+        mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+    }
+    // ---- phase 2: 1x1 strided residual conv over the block input (models/base.py:372-374)
+    if (conv_res) {
+        const int fa = p.stride * ta + p.res_off;
+        const int span = (p.stride * (tb - ta) + 1) * V;
+        const float *seg_base = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+        const int64_t cs = (int64_t)p.Tres * V;
+        const float *wbase = p.wres + m0;
+        ws.setup(1, p.CresPad, p.Mpad, tid);
+        bs.setup(fa * V, span, p.Tres * V, lane);
+        ws.issue(wbase);
+        bs.issue(seg_base, p.Cres, cs, 0, wave);
+        int c0 = 0;
+        for (; c0 + KC < p.CresPad; c0 += KC) {
+            __syncthreads();
+            ws.commit(Wl);
+            bs.commit(Bl, p.ldb, wave);
+            __syncthreads();
+            ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
+            bs.issue(seg_base, p.Cres, cs, c0 + KC, wave);
+            mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
+        }
+        __syncthreads();
+        ws.commit(Wl);
+        bs.commit(Bl, p.ldb, wave);
+        __syncthreads();
+        issue_epilogue_loads();
+        mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
+    }
+    if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
+    // ---- epilogue: + bias (+ identity residual), ReLU, predicated stores.
+    // C/D map: col = lane&31, row = (g&3) + 8(g>>2) + 4(lane>>5).  A plain store of accumulator register g
+    // writes two 128-B half rows (rows r and r+4).  v_permlane32_swap of the ni=0 / ni=1 registers gives each
+    // lane half the SAME row instead: lanes 0-31 columns 0-31, lanes 32-63 columns 32-63 of row r (first
+    // result) and of row r+4 (second) -> every store instruction writes one 256-B contiguous row segment.
+    {
+        const int qb = q0 + wn * 64 + lane;                    // column of this lane after the swap
+        const bool qv = qb < Q;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int co_own = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
+                float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                // sw[0]: row (co_own - 4*kh), this lane's column qb; sw[1]: row (co_own - 4*kh + 4)
+                const int row0 = co_own - 4 * kh;
+                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * Q + qb] = __uint_as_float(sw[0]);
+                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * Q + qb] = __uint_as_float(sw[1]);
+            }
+    }
+    if (p.stamps && tid == 0) {
+        unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 6;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+        o[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+// pick the <MT, NJ> instantiation, raise its dynamic-LDS cap, launch
+template <typename P, typename K>
+static int launch_stage(bool big, bool small_span, dim3 grid, size_t lds, hipStream_t s, const P &p, K k128a, K k128b,
+                        K k64a, K k64b) {
+    K k = big ? (small_span ? k128a : k128b) : (small_span ? k64a : k64b);
+    if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
+    hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
+                                 const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,
+                                 int stride, int pad, int res_mode, int c_res, int t_res, int res_off, int relu,
+                                 void *stream) {
+    if (!y || !w || !bias || !out) CSK_FAIL("tcn_stage: null pointer");
+    if (n_seg <= 0 || c <= 0 || c_out <= 0 || t_in <= 0 || V < 2 || V > 64) CSK_FAIL("tcn_stage: bad dims");
+    if (k < 1 || k > 9 || stride < 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage: bad k/stride/pad (k <= 9)");
+    if (t_in + 2 * pad < k) CSK_FAIL("tcn_stage: t_in too short for kernel");
+    const int t_out = (t_in + 2 * pad - k) / stride + 1;
+    if (res_mode != CSK_RES_NONE) {
+        if (!x_res) CSK_FAIL("tcn_stage: residual requested without x_res");
+        if (res_mode == CSK_RES_IDENTITY && c_res != c_out) CSK_FAIL("tcn_stage: identity residual needs c_res == c_out");
+        if (res_mode == CSK_RES_CONV && !w_res) CSK_FAIL("tcn_stage: conv residual without w_res");
+        if ((t_out - 1) * stride + res_off >= t_res || res_off < 0) CSK_FAIL("tcn_stage: residual frames out of range");
+    }
+    if ((int64_t)t_in * V >= (1 << 26)) CSK_FAIL("tcn_stage: T*V too large for 32-bit position arithmetic");
+    TcnParams p;
+    p.y = y; p.w = w; p.xres = x_res ? x_res : y; p.wres = w_res; p.bias = bias; p.out = out;
+    p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.stride = stride; p.pad = pad;
+    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD);
+    p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
+    p.stamps = csk_diag_stamps();
+    p.prio = !csk_diag_flag("CSK_NOPRIO");
+    const bool big = (p.Mpad % 128) == 0;
+    const int MT = big ? 128 : 64, NT = 16384 / MT;
+    const int max_dt = (NT + V - 2) / V;
+    p.ldb = round_up((stride * max_dt + k) * V, 4);
+    const size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
+    if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
+    const int Q = t_out * V;
+    p.qtiles = (Q + NT - 1) / NT; p.mtiles = p.Mpad / MT;
+    if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage: grid too large");
+    dim3 grid(p.qtiles * p.mtiles * n_seg);
+    const int nj = (p.ldb + 63) / 64;
+    if (nj > 14) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
+    return launch_stage(big, nj <= 9, grid, lds, (hipStream_t)stream, p,
+                        tcn_stage_kernel<128, 9>, tcn_stage_kernel<128, 14>, tcn_stage_kernel<64, 9>, tcn_stage_kernel<64, 14>);
+}
+
