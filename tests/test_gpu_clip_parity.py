@@ -155,3 +155,26 @@ def test_general_gcn_kernel_matches_sparse_fast_path():
         subprocess.check_call([sys.executable, "-c", code, path], env=env)
         outs.append(torch.load(path))
     assert max_err(outs[0], outs[1]) <= 1e-5
+
+
+def test_clip_forward_is_graph_capturable():
+    """include/cskel.h promises launches without allocation or synchronisation: a whole 10-block forward must be
+    capturable into a hipGraph and replay bit-identically."""
+    a, sd, x = g6_state_dict("ntu")
+    net = pkg.StGcn(_A()).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    xd = x[:1].to(DEV)
+    for _ in range(2):
+        ref = net(xd)                     # warm-up: folds weights, raises the LDS caps, fills the caching allocator
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = net(xd)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    xd.copy_(x[1:2].to(DEV))              # new input in the captured buffer -> replay computes the new result
+    g.replay()
+    torch.cuda.synchronize()
+    assert max_err(out.cpu(), a["logits"][1:2]) <= TOL
