@@ -1,0 +1,197 @@
+// Microbenchmark: ceiling of the "4 LDS fragment reads + 4 fp32 MFMA per k-step" inner loop used by the stage
+// kernels, at 2 waves/SIMD (two 256-thread workgroups per CU), against variants.  hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int MT = 128, KC = 8, LDB = 376, TAPS = 9;
+
+// VARIANT 0: as in tcn_stage_kernel (LDS operands, software-pipelined reads, sched_barrier fences)
+// VARIANT 1: LDS operands, plain loop (compiler schedules)
+// VARIANT 2: operands in registers (no LDS traffic) -> pure MFMA issue ceiling at this occupancy
+// VARIANT 3: LDS operands, 16x16x4 MFMAs (16 accumulators of 4 regs)
+template <int VARIANT>
+__global__ __launch_bounds__(256, 2) void loop_kernel(float *out, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem, *Bl = smem + TAPS * KC * MT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < TAPS * KC * MT + KC * LDB; i += 256) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
+    __syncthreads();
+    const int offA = (wave & 1) * 64 + l31, off0 = (wave >> 1) * 64 + l31, off1 = off0 + 32;
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    f32x4 acc4[16];
+    for (int a = 0; a < 16; ++a) for (int g = 0; g < 4; ++g) acc4[a][g] = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        if (VARIANT == 0) {
+            const float *wr = Wl + offA + kh * MT, *br = Bl + kh * LDB;
+            float a0 = wr[0], a1 = wr[32], b0 = br[off0], b1 = br[off1];
+            for (int r = 0; r < TAPS; ++r) {
+                const int rn = r + 1 < TAPS ? r + 1 : TAPS - 1;
+                const float *wn = Wl + rn * (KC * MT) + offA + kh * MT, *bn = Bl + rn * 25 + kh * LDB;
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    float na0, na1, nb0, nb1;
+                    if (s + 1 < KC / 2) { na0 = wr[(2*s+2)*MT]; na1 = wr[(2*s+2)*MT+32]; nb0 = br[(2*s+2)*LDB+off0]; nb1 = br[(2*s+2)*LDB+off1]; }
+                    else { na0 = wn[0]; na1 = wn[32]; nb0 = bn[off0]; nb1 = bn[off1]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+                }
+                wr = wn; br = bn;
+            }
+        } else if (VARIANT == 1) {
+            for (int r = 0; r < TAPS; ++r) {
+                const float *wr = Wl + r * (KC * MT) + offA + kh * MT, *br = Bl + r * 25 + kh * LDB;
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    const float a0 = wr[2*s*MT], a1 = wr[2*s*MT+32], b0 = br[2*s*LDB+off0], b1 = br[2*s*LDB+off1];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        } else if (VARIANT == 2) {
+            float a0 = Wl[offA], a1 = Wl[offA + 32], b0 = Bl[off0], b1 = Bl[off1];
+            for (int r = 0; r < TAPS; ++r) {
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    asm volatile("" : "+v"(a0), "+v"(b0));
+                }
+            }
+        } else {
+            const int l15 = lane & 15, k4 = lane >> 4;
+            for (int r = 0; r < TAPS; ++r) {
+                const float *wr = Wl + r * (KC * MT) + (wave & 1) * 64 + l15 + k4 * MT, *br = Bl + r * 25 + (wave >> 1) * 64 + l15 + k4 * LDB;
+#pragma unroll
+                for (int s = 0; s < KC / 4; ++s) {
+                    float a[4], b[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { a[m] = wr[4*s*MT + 16*m]; b[m] = br[4*s*LDB + 16*m]; }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc4[m*4+n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc4[m*4+n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) s += acc[a][b][g];
+    for (int a = 0; a < 16; ++a) for (int g = 0; g < 4; ++g) s += acc4[a][g];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+// STRUCT variants: the plain loop plus, cumulatively, the per-chunk structure of tcn_stage_kernel
+//   level 1: two __syncthreads per chunk      level 2: + commit of 9 f32x4 + 18 dwords per thread to LDS
+//   level 3: + 27 global loads per thread per chunk (next chunk's operands, register prefetch), three bursts
+template <int LEVEL>
+__global__ __launch_bounds__(256, 2) void struct_kernel(float *out, const float *gw, const float *gb, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem, *Bl = smem + TAPS * KC * MT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < TAPS * KC * MT + KC * LDB; i += 256) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
+    __syncthreads();
+    const int offA = (wave & 1) * 64 + l31, off0 = (wave >> 1) * 64 + l31, off1 = off0 + 32;
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    f32x4 wv[9];
+    float bv[18];
+    for (int u = 0; u < 9; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(gw + (u * 256 + tid) * 4);
+    for (int u = 0; u < 18; ++u) bv[u] = gb[(size_t)blockIdx.x * 65536 + u * 256 + tid];
+    for (int c = 0; c < chunks; ++c) {
+        if (LEVEL >= 1) __syncthreads();
+        if (LEVEL >= 2) {
+#pragma unroll
+            for (int u = 0; u < 9; ++u) *reinterpret_cast<f32x4 *>(Wl + (u * 256 + tid) * 4) = wv[u];
+#pragma unroll
+            for (int u = 0; u < 18; ++u) Bl[(u >> 1) % KC * LDB + (u & 1) * 128 + (tid & 127) + (tid >> 7) * 0] = bv[u] + (float)(tid >> 7);
+        }
+        if (LEVEL >= 1) __syncthreads();
+        const float *gwc = gw + (size_t)((c + 1) & 31) * 9216, *gbc = gb + (size_t)blockIdx.x * 65536 + (size_t)((c + 1) & 7) * 4608;
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3) {
+            if (LEVEL >= 3) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int u = 3 * g3 + j;
+                    wv[u] = *reinterpret_cast<const f32x4 *>(gwc + (u * 256 + tid) * 4);
+                    bv[2 * u] = gbc[2 * u * 256 + tid];
+                    bv[2 * u + 1] = gbc[(2 * u + 1) * 256 + tid];
+                }
+            }
+            for (int r = 3 * g3; r < 3 * g3 + 3; ++r) {
+                const float *wr = Wl + r * (KC * MT) + offA + kh * MT, *br = Bl + r * 25 + kh * LDB;
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    const float a0 = wr[2*s*MT], a1 = wr[2*s*MT+32], b0 = br[2*s*LDB+off0], b1 = br[2*s*LDB+off1];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) s += acc[a][b][g];
+    for (int u = 0; u < 9; ++u) s += wv[u][0];
+    for (int u = 0; u < 18; ++u) s += bv[u];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int L> double run_struct(int chunks, int blocks) {
+    float *out, *gw, *gb;
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipMalloc(&gw, (size_t)32 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)32 * 9216 * 4 + 65536);
+    hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
+    const size_t lds = (TAPS * KC * MT + KC * LDB) * 4;
+    hipFuncSetAttribute((const void *)struct_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(struct_kernel<L>, dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(struct_kernel<L>, dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    hipFree(out); hipFree(gw); hipFree(gb);
+    const double flops = (double)blocks * 4 * chunks * TAPS * (KC / 2) * 4 * 4096.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
+template <int V> double run(int chunks, int blocks) {
+    float *out; hipMalloc(&out, (size_t)blocks * 256 * 4);
+    const size_t lds = (TAPS * KC * MT + KC * LDB) * 4;
+    hipFuncSetAttribute((const void *)loop_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(loop_kernel<V>, dim3(blocks), dim3(256), lds, 0, out, chunks);
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(loop_kernel<V>, dim3(blocks), dim3(256), lds, 0, out, chunks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    hipFree(out);
+    const double flops = (double)blocks * 4 /*waves*/ * chunks * TAPS * (KC / 2) * 4 * 4096.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
+int main() {
+    const int chunks = 64, blocks = 512 * 6;     // 2 workgroups per CU resident, 6 rounds
+    printf("variant 0 (as shipped: LDS + pipelined reads + fences): %.1f TFLOP/s\n", run<0>(chunks, blocks));
+    printf("variant 1 (LDS, compiler-scheduled):                    %.1f TFLOP/s\n", run<1>(chunks, blocks));
+    printf("variant 2 (register operands, no LDS):                  %.1f TFLOP/s\n", run<2>(chunks, blocks));
+    printf("variant 3 (LDS, 16x16x4 MFMA):                          %.1f TFLOP/s\n", run<3>(chunks, blocks));
+    printf("struct 0 (plain loop, chunked in 3 tap segments):         %.1f TFLOP/s\n", run_struct<0>(chunks, blocks));
+    printf("struct 1 (+ 2 barriers per chunk):                      %.1f TFLOP/s\n", run_struct<1>(chunks, blocks));
+    printf("struct 2 (+ LDS commit of 9 f32x4 + 18 dwords):         %.1f TFLOP/s\n", run_struct<2>(chunks, blocks));
+    printf("struct 3 (+ 27 global prefetch loads in 3 bursts):      %.1f TFLOP/s\n", run_struct<3>(chunks, blocks));
+    return 0;
+}
