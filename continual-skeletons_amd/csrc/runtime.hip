@@ -18,13 +18,17 @@
 #include "mfma_core.h"
 
 int csk_ensure_lds(const void *kernel, size_t bytes) {
+    // the attribute is per (device, kernel); one process normally drives one GPU, but do not rely on it
     static std::mutex mu;
-    static std::unordered_map<const void *, size_t> cap;
+    static std::unordered_map<unsigned long long, size_t> cap;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long key = (unsigned long long)(uintptr_t)kernel ^ ((unsigned long long)(dev + 1) << 56);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cap.find(kernel);
+    auto it = cap.find(key);
     if (it != cap.end() && it->second >= bytes) return 0;
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) cap[kernel] = bytes;
+    if (e == hipSuccess) cap[key] = bytes;
     return (int)e;
 }
 
