@@ -17,6 +17,7 @@ live with HIP events on the launch stream, against the dense fp32 MFMA peak (157
 `cpu_baseline` times the CPU oracle (a port of the reference's op sequence, see oracle/) on the host cores.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -123,7 +124,7 @@ def step_flops_per_cycle(nm, c_in=3, V=25):
     return 2 * g * nm, 2 * t * nm
 
 
-def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1, native_plan=True):
+def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1, native_plan=True, fpl=4):
     """CoST-GCN online inference: `streams` concurrent streams per GPU, persistent ring-buffer state; one
     cycle = 4 consecutive frames (the stack's stride pattern) = one prediction per stream.  With shards > 1 the
     stream axis is split into independent shards advanced on separate HIP streams (parallel.StreamShards)."""
@@ -141,8 +142,8 @@ def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, paral
 
     def cycle():
         nonlocal fi
-        out = eng.forward_cycle([frames[(fi + f) % 8] for f in range(4)])     # 4 frames, one launch pair per block
-        fi += 4
+        out = eng.forward_cycle([frames[(fi + f) % 8] for f in range(fpl)])   # fpl frames, one launch pair per block
+        fi += fpl
         return parallel.all_gather_logits(out) if world > 1 else out
 
     with LaunchTimer(pkg, "tcn_step_launch") as lt:
@@ -210,6 +211,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1024, help="concurrent CoST-GCN streams per GPU")
     ap.add_argument("--step-cycles", type=int, default=16, help="timed 4-frame cycles of the online workload")
     ap.add_argument("--stream-shards", type=int, default=2, help="independent stream shards on separate HIP streams")
+    ap.add_argument("--frames-per-launch", type=int, default=4, help="frames advanced per launch cycle of the online workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -278,6 +280,7 @@ def main():
         assert out.shape == (B * world, NTU["classes"]) and bool(torch.isfinite(out).all())
         dt = max_over_ranks(dt)
         del x, out, net
+        gc.collect()                 # engines hold reference cycles (state-dict hooks); free their slabs now
         torch.cuda.empty_cache()
         clips = B * world * args.steps
         flops_launch = tcn_flops_per_clip_forward(B * NTU["M"]) / 10.0       # average over the 10 launches / step
@@ -304,22 +307,32 @@ def main():
         }
 
     if do_step:
-        sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist, args.stream_shards)
+        sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist, args.stream_shards, fpl=args.frames_per_launch)
         sdt = max_over_ranks(sdt)
         # kernel-level timing: launches must not overlap and must go through the Python hook -> short single-shard pass
+        gc.collect()                 # engines hold reference cycles (state-dict hooks); free their slabs now
         torch.cuda.empty_cache()
         _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1, native_plan=False)
         kcycles = 4
         gfl, tfl = step_flops_per_cycle(args.streams * NTU["M"])
-        fps = 4 * args.streams * world * args.step_cycles / sdt
+        fps = args.frames_per_launch * args.streams * world * args.step_cycles / sdt
         ach = tfl * kcycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0
+        thr = None
+        if args.frames_per_launch != 8:      # throughput mode: two stride cycles per launch (adds 4 frames of latency)
+            gc.collect()
+            torch.cuda.empty_cache()
+            tdt, _, _, _ = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist,
+                                             args.stream_shards, fpl=8)
+            tdt = max_over_ranks(tdt)
+            thr = {"frames_per_launch": 8, "value": round(8 * args.streams * world * args.step_cycles / tdt, 1),
+                   "unit": "frames/s"}
         step_info = {"metric": "skeleton frames/sec (CoST-GCN online step, NTU-60 shape)", "value": round(fps, 1),
-                     "unit": "frames/s", "streams_per_gpu": args.streams, "stream_shards": args.stream_shards, "frames_per_launch": 4, "ms_per_frame_step": round(sdt / args.step_cycles / 4 * 1e3, 4),
+                     "unit": "frames/s", "streams_per_gpu": args.streams, "stream_shards": args.stream_shards, "frames_per_launch": args.frames_per_launch, "ms_per_frame_step": round(sdt / args.step_cycles / args.frames_per_launch * 1e3, 4),
                      "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
                      "roofline": {"bound": "mfma", "kernel": "tcn_step_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,
                                   "avg_launch_ms": round(stcn_ms / max(1, sn), 4), "traffic": None},
-                     "cpu_baseline": cpu_step, "config": "BASELINE.json configs[2]"}
+                     "throughput_mode": thr, "cpu_baseline": cpu_step, "config": "BASELINE.json configs[2]"}
         if line is None:          # --workload step: the online metric is the primary one
             line = {"metric": step_info["metric"], "value": step_info["value"], "unit": "frames/s", "n_gpus": world,
                     "steps": args.step_cycles, "warmup": 2, "ms_per_step": round(sdt / args.step_cycles * 1e3, 3),

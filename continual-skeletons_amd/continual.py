@@ -13,9 +13,9 @@ Protocol (anchored on the reference's tests, see oracle/stgcn_oracle.py:CoBlockO
   * the emission of step s equals the clip block's output at t = (s - delay) / S;
   * ``forward_steps(x, pad_end)``: all frames, optionally flushed with ``padding`` zero post-GCN frames;
   * ``clean_state()`` zeroes the window (zero state == the clip conv's left zero padding).
-State layout (channel-major, see include/cskel.h): per block a y ring [12][C_out][P] and an output ring
-[8][C_out][P]; the output ring of block l is the input/residual history of block l+1, so the
-residual FIFO (``co.Delay``) costs no copy.  ``engine_advance`` consumes up to 4 frames per call (one
+State layout (channel-major, see include/cskel.h): per block a y ring [16][C_out][P] and an output ring
+[16][C_out][P]; the output ring of block l is the input/residual history of block l+1, so the
+residual FIFO (``co.Delay``) costs no copy.  ``engine_advance`` consumes up to 8 frames per call (4 = one
 stride cycle of the 10-block stack) with one GCN launch and one multi-emission TCN launch per block,
 which is what fills the GPU at ~1000 streams; per-frame stepping is the same code with r = 1.
 """
@@ -31,9 +31,9 @@ from . import blocks, fold, native
 from .blocks import GraphConvolution, SpatioTemporalBlock, TemporalConvolution, _Folded, init_weights, unity, zero
 from .models import layer_table
 
-HIST = 8     # depth of an input / output history ring (>= residual lag 4 + the frames of one 4-frame cycle)
-YRING = 12   # depth of the post-GCN ring: k-1 = 8 window frames + up to 4 new frames per launch
-MAX_CYCLE = 4
+HIST = 16    # depth of an input / output history ring (>= residual lag 4 + the frames of the longest cycle)
+YRING = 16   # depth of the post-GCN ring: k-1 = 8 window frames + up to 8 new frames per launch
+MAX_CYCLE = 8
 
 
 def _round4(n: int) -> int:
@@ -205,7 +205,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             self._state.zero_()
 
     def engine_advance(self, r: int, n_frames: int, V: int, flush: bool = False):
-        """Consume ``r`` (<= 4) frames already stored in ``xin[(s .. s+r-1) % HIST]`` (channel-major).  Returns
+        """Consume ``r`` (<= MAX_CYCLE) frames already stored in ``xin[(s .. s+r-1) % HIST]`` (channel-major).  Returns
         ``(first_out_slot, n_emit)`` for the emissions of these frames, or None.  ``flush`` pushes zero
         post-GCN frames instead (end padding)."""
         st, k = self._state, self.kernel_size
@@ -535,8 +535,8 @@ class CoStGcn(_Folded):
         return outs[-1] if outs else None
 
     def forward_cycle(self, frames):
-        """Up to 4 consecutive frames in one go (list of (N, C, V, M) tensors): same results as calling
-        ``forward_step`` on each, with 4x fewer and 4x larger launches.  Returns the list of logits emitted."""
+        """Up to MAX_CYCLE (8) consecutive frames in one go (list of (N, C, V, M) tensors): same results as calling
+        ``forward_step`` on each, with len(frames)x fewer and larger launches (4 = one stride cycle of the stack).  Returns the list of logits emitted."""
         return self._cycle(frames)[2]
 
     def forward_steps(self, x, pad_end=False, update_state=True):

@@ -48,3 +48,46 @@ unsigned long long *csk_diag_stamps() {
     const char *d = getenv("CSK_STAMPS");
     return d ? (unsigned long long *)strtoull(d, nullptr, 0) : nullptr;
 }
+
+// ---- stream concurrency probe (include/cskel.h: csk_stream_overlap_probe) -----------------------------------------
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();                 // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int csk_stream_overlap_probe(void *stream_a, void *stream_b, int spin_us, float *ratio) {
+    if (!ratio) CSK_FAIL("stream_overlap_probe: null pointer");
+    if (spin_us < 10 || spin_us > 100000) CSK_FAIL("stream_overlap_probe: spin_us must be in [10, 100000], got %d", spin_us);
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    const long long ticks = 100LL * spin_us;
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    hipError_t err = hipSuccess;
+    float alone = 0.f, ta = 0.f, tb = 0.f;
+#define CSK_TRY(x) do { err = (x); if (err != hipSuccess) goto done; } while (0)
+    CSK_TRY(hipEventCreate(&e0)); CSK_TRY(hipEventCreate(&ea)); CSK_TRY(hipEventCreate(&eb));
+    for (int pass = 0; pass < 2; ++pass) {               // pass 0 also absorbs the first-launch cost
+        CSK_TRY(hipEventRecord(e0, a));
+        spin_kernel<<<1, 64, 0, a>>>(ticks);
+        CSK_TRY(hipEventRecord(ea, a));
+        CSK_TRY(hipStreamSynchronize(a));
+        CSK_TRY(hipEventElapsedTime(&alone, e0, ea));
+    }
+    CSK_TRY(hipStreamSynchronize(b));
+    CSK_TRY(hipEventRecord(e0, a));
+    CSK_TRY(hipStreamWaitEvent(b, e0, 0));
+    spin_kernel<<<1, 64, 0, a>>>(ticks);
+    spin_kernel<<<1, 64, 0, b>>>(ticks);
+    CSK_TRY(hipEventRecord(ea, a));
+    CSK_TRY(hipEventRecord(eb, b));
+    CSK_TRY(hipStreamSynchronize(a));
+    CSK_TRY(hipStreamSynchronize(b));
+    CSK_TRY(hipEventElapsedTime(&ta, e0, ea));
+    CSK_TRY(hipEventElapsedTime(&tb, e0, eb));
+    *ratio = (ta > tb ? ta : tb) / (alone > 1e-6f ? alone : 1e-6f);
+done:
+#undef CSK_TRY
+    if (e0) (void)hipEventDestroy(e0);
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    return (int)err;
+}

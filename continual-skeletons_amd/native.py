@@ -10,12 +10,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 # name -> argtypes; mirrors include/cskel.h line by line
 SIGNATURES = {
     "csk_abi_version": [],
+    "csk_stream_overlap_probe": [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)],
     "csk_gcn_stage_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _p],
     "csk_tcn_stage_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "csk_input_norm_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _p],

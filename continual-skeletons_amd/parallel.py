@@ -7,8 +7,13 @@ logits ``(N/world, classes)`` -- RCCL over xGMI when the process group is "nccl"
 1024 clips/GPU, i.e. latency-bound, so it is issued as a single in-place collective on the compute
 stream.  The two skeletons (M) of a clip never split: sharding is over whole clips.
 """
+import ctypes
+import warnings
+
 import torch
 import torch.distributed as dist
+
+from . import native
 
 
 def shard_bounds(n_total: int, rank: int, world: int):
@@ -42,6 +47,37 @@ def all_gather_ragged(local: torch.Tensor, n_total: int, group=None) -> torch.Te
     return torch.cat([gathered[r, : sizes[r]] for r in range(world)], dim=0)
 
 
+def streams_overlap(a, b, spin_us: int = 200) -> bool:
+    """True if HIP streams ``a`` and ``b`` run concurrently (they sit on different hardware queues)."""
+    ratio = ctypes.c_float(0.0)
+    native.check(native.lib().csk_stream_overlap_probe(a.cuda_stream, b.cuda_stream, spin_us, ctypes.byref(ratio)),
+                 "csk_stream_overlap_probe")
+    return ratio.value < 1.5
+
+
+def concurrent_streams(n: int, device, candidates: int = 16):
+    """``n`` HIP streams that run concurrently with each other and with the current stream.
+
+    HIP multiplexes streams onto 4 hardware queues (GPU_MAX_HW_QUEUES) in creation order, and PyTorch hands out
+    its pool streams round-robin, so which shards would share a queue -- and silently serialise -- depends on how
+    many streams the process (RCCL included) created before.  Candidates are therefore probed
+    (csk_stream_overlap_probe) and only mutually concurrent ones are kept.  If the hardware queues run out the
+    remaining shards share (a warning says so)."""
+    cur = torch.cuda.current_stream(device)
+    chosen, spare = [], []
+    for _ in range(candidates):
+        if len(chosen) == n:
+            break
+        s = torch.cuda.Stream(device=device)
+        (chosen if all(streams_overlap(s, o) for o in [cur] + chosen) else spare).append(s)
+    if len(chosen) < n:
+        warnings.warn(f"only {len(chosen)} of {n} stream shards get a hardware queue of their own; the rest share")
+        chosen += spare[: n - len(chosen)]
+        while len(chosen) < n:
+            chosen.append(torch.cuda.Stream(device=device))
+    return chosen
+
+
 class StreamShards:
     """Intra-GPU sharding of the continual stream axis over HIP streams.
 
@@ -54,7 +90,7 @@ class StreamShards:
     def __init__(self, make_model, n_streams: int, n_shards: int, device):
         self.bounds = [shard_bounds(n_streams, r, n_shards) for r in range(n_shards)]
         self.models = [make_model() for _ in range(n_shards)]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_shards)] if n_shards > 1 else [None]
+        self.streams = concurrent_streams(n_shards, device) if n_shards > 1 else [None]
         self.device = device
 
     def forward_cycle(self, frames):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 3
+#define CSK_ABI_VERSION 4
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -37,6 +37,17 @@ extern "C" {
 int csk_abi_version(void);
 /* thread-local text of the last argument error */
 const char *csk_last_error(void);
+
+/*
+ * Do two HIP streams execute concurrently on this device?  HIP multiplexes its streams onto a few hardware queues
+ * (4 by default); two streams that land on the same queue run strictly one after the other, which silently turns the
+ * stream shards of the continual path (parallel.py:StreamShards; the reference has no counterpart, it steps one
+ * Python module at a time) into a serial schedule.  Launches one single-wavefront kernel that spins for spin_us
+ * microseconds on each stream behind a common start event and writes
+ *   *ratio = (time until both have finished) / (time of one alone):   ~1 = concurrent, ~2 = serialised.
+ * Synchronises both streams.  No other work should be in flight on either stream.
+ */
+int csk_stream_overlap_probe(void *stream_a, void *stream_b, int spin_us, float *ratio);
 
 /*
  * GraphConvolution.forward, models/base.py:260-270 (and its per-frame use by CoGraphConvolution,
@@ -180,9 +191,9 @@ int csk_fuse_rank_f32(const float *const *preds, int n_streams, int use_max, int
  * frames (input norm, per block one GCN-stage + one multi-emission TCN-step launch, spatial pool, temporal
  * window mean, FC), with the ring-slot / stride-phase bookkeeping kept in the plan.  No allocation, no sync.
  * ------------------------------------------------------------------------------------------------ */
-#define CSK_CO_HIST 8    /* depth of input / output history rings  */
-#define CSK_CO_YRING 12  /* depth of the post-GCN rings            */
-#define CSK_CO_MAX_CYCLE 4
+#define CSK_CO_HIST 16   /* depth of input / output history rings  */
+#define CSK_CO_YRING 16  /* depth of the post-GCN rings            */
+#define CSK_CO_MAX_CYCLE 8
 
 typedef struct csk_co_layer {
     int32_t c_in, c_out, stride, res_kind;   /* res_kind: CSK_RES_NONE / IDENTITY / CONV (block residual) */

