@@ -26,6 +26,7 @@ struct TcnParams {
     int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
     int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
     unsigned vmagic, mtiles, qtiles;
+    int nt;                       // positions per tile actually used (<= 16384 / MT)
     int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
@@ -43,16 +44,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     const int l31 = lane & 31, kh = lane >> 5;
     // work item -> (m-tile fastest: shares the activation tile; then position tile: shares halos; then segment)
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
+    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * p.nt;
     const int seg = (int)(wid / (p.mtiles * p.qtiles));
     const int V = p.V, Q = p.Tout * V;
-    const int qend = min(q0 + NT, Q);
+    const int qend = min(q0 + p.nt, Q);          // p.nt == NT unless the staged span had to be narrowed (large stride * V)
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
 
     int off[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int q = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+        const int q = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
         const int t = div_magic(q, p.vmagic);
         off[ni] = p.stride * (t - ta) * V + (q - t * V);
     }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+            const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
             const int t = div_magic(qc, p.vmagic);
             const int qres = ident ? (t * p.stride + p.res_off) * V + (qc - t * V) : 0;
 #pragma unroll
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     // result) and of row r+4 (second) -> every store instruction writes one 256-B contiguous row segment.
     {
         const int qb = q0 + wn * 64 + lane;                    // column of this lane after the swap
-        const bool qv = qb < Q;
+        const bool qv = qb < qend;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -253,12 +254,20 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.prio = !csk_diag_flag("CSK_NOPRIO");
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
-    const int max_dt = (NT + V - 2) / V;
-    p.ldb = round_up((stride * max_dt + k) * V, 4);
+    // the register staging holds <= 14 x 64 positions of an activation row; tiles whose input span (stride * frames
+    // + k taps) * V is longer than that (stride 3 with V > 32, ...) are narrowed: a tile then covers p.nt < NT output
+    // positions and the remaining MFMA columns idle.  Never the case for the ST-GCN shapes (V <= 25, stride <= 2).
+    p.nt = NT;
+    for (;;) {
+        const int max_dt = (p.nt + V - 2) / V;
+        p.ldb = round_up((stride * max_dt + k) * V, 4);
+        if ((p.ldb + 63) / 64 <= 14 || p.nt == 1) break;
+        p.nt = p.nt > 16 ? p.nt - 16 : 1;
+    }
     const size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
     if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = t_out * V;
-    p.qtiles = (Q + NT - 1) / NT; p.mtiles = p.Mpad / MT;
+    p.qtiles = (Q + p.nt - 1) / p.nt; p.mtiles = p.Mpad / MT;
     if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage: grid too large");
     dim3 grid(p.qtiles * p.mtiles * n_seg);
     const int nj = (p.ldb + 63) / 64;

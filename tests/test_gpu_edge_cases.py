@@ -99,3 +99,84 @@ def test_stream_shards_get_concurrent_hardware_queues():
     assert all(parallel.streams_overlap(p, cur) for p in picked)
     with pytest.raises(RuntimeError, match="spin_us"):
         parallel.streams_overlap(s, cur, spin_us=1)
+
+
+def _random_adjacency(v, dense, g):
+    """(3, V, V): dense random weights (general GCN kernel) or a skeleton-like pattern with <= 1 / 1 / 4 non-zeros
+    per column (sparse kernel), random positions and values."""
+    if dense:
+        return torch.rand(3, v, v, generator=g) / v
+    A = torch.zeros(3, v, v)
+    for w in range(v):
+        A[0, w, w] = float(torch.rand(1, generator=g)) + 0.5
+        A[1, int(torch.randint(v, (1,), generator=g)), w] = float(torch.rand(1, generator=g)) + 0.1
+        for src in torch.randperm(v, generator=g)[: int(torch.randint(1, min(4, v) + 1, (1,), generator=g))]:
+            A[2, int(src), w] = float(torch.rand(1, generator=g)) + 0.1
+    return A
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_block_random_sweep(seed):
+    """Seeded random blocks: channel counts off every padding granule, strides 1-3, clip lengths 1-90, 2-40 joints,
+    random adjacencies of both kinds, all three residual forms -- HIP block vs the oracle."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    v, stride, res = ri(2, 40), ri(1, 3), bool(ri(0, 3))
+    ci = ri(1, 150)
+    co = ci if (res and ri(0, 1)) else ri(1, 150)
+    T, N = ri(1, 90), ri(1, 4)
+    A = _random_adjacency(v, dense=bool(seed % 2), g=g)
+    m = pkg.SpatioTemporalBlock(ci, co, A, stride, res).eval()
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("graph_attn") or ("bn" in name and name.endswith("weight")):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand(prm.shape, generator=g) - 0.5)
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
+    sd = {k: t.clone() for k, t in m.state_dict().items()}
+    x = torch.rand(N, ci, T, v, generator=g)
+    with torch.no_grad():
+        want = o.st_block(x, sd, "", stride, res)
+    got = m.to(DEV)(x.to(DEV)).cpu()
+    assert got.shape == want.shape, (ci, co, stride, res, T, N, v)
+    assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max())), (ci, co, stride, res, T, N, v)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_continual_block_random_sweep(seed):
+    """Seeded random continual blocks: stepping the whole clip with pad_end reproduces the clip oracle
+    (tests/test_cost_gcn.py:66-68) for random channel counts, stride 1-2, stream counts, joint counts and
+    adjacencies of both kinds."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    v, stride, res = ri(2, 33), ri(1, 2), bool(ri(0, 3))
+    ci = ri(1, 140)
+    co = ci if (res and ri(0, 1)) else ri(1, 140)
+    T, N = ri(9, 40), ri(1, 5)
+    A = _random_adjacency(v, dense=bool(seed % 2), g=g)
+    ref = pkg.SpatioTemporalBlock(ci, co, A, stride, res).eval()
+    with torch.no_grad():
+        for name, prm in ref.named_parameters():
+            if name.endswith("graph_attn") or ("bn" in name and name.endswith("weight")):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand(prm.shape, generator=g) - 0.5)
+        for name, buf in ref.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
+    sd = {k: t.clone() for k, t in ref.state_dict().items()}
+    x = torch.rand(N, ci, T, v, generator=g)
+    with torch.no_grad():
+        want = o.st_block(x, sd, "", stride, res)
+    blk = pkg.CoSpatioTemporalBlock(ci, co, A, stride=stride, residual=res, padding=4).eval()
+    blk.load_state_dict(sd, strict=True)
+    got = blk.to(DEV).forward_steps(x.to(DEV), pad_end=True).cpu()
+    assert got.shape == want.shape, (ci, co, stride, res, T, N, v)
+    assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max())), (ci, co, stride, res, T, N, v)
