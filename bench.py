@@ -191,9 +191,9 @@ def cpu_baseline_step(seed):
                 sample=f"{n} steady-state frames of one NTU-60 stream after 76 warm-up frames, oracle.CoStGcnOracle")
 
 
-def load_traffic():
+def load_traffic(name="traffic_tcn_stage.json"):
     """Per-launch HBM bytes of the dominant kernel from the committed PMC summary (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "traffic_tcn_stage.json")
+    p = os.path.join(ROOT, "profiles", name)
     if os.path.exists(p):
         with open(p) as f:
             return json.load(f)
@@ -317,6 +317,7 @@ def main():
         gfl, tfl = step_flops_per_cycle(args.streams * NTU["M"])
         fps = args.frames_per_launch * args.streams * world * args.step_cycles / sdt
         ach = tfl * kcycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0
+        straffic = load_traffic("traffic_tcn_step.json")
         thr = None
         if args.frames_per_launch != 8:      # throughput mode: two stride cycles per launch (adds 4 frames of latency)
             gc.collect()
@@ -331,7 +332,8 @@ def main():
                      "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
                      "roofline": {"bound": "mfma", "kernel": "tcn_step_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,
-                                  "avg_launch_ms": round(stcn_ms / max(1, sn), 4), "traffic": None},
+                                  "avg_launch_ms": round(stcn_ms / max(1, sn), 4),
+                                  "traffic": straffic["hbm_bytes_per_launch"] if straffic and straffic.get("streams") == args.streams else None},
                      "throughput_mode": thr, "cpu_baseline": cpu_step, "config": "BASELINE.json configs[2]"}
         if line is None:          # --workload step: the online metric is the primary one
             line = {"metric": step_info["metric"], "value": step_info["value"], "unit": "frames/s", "n_gpus": world,

@@ -16,6 +16,9 @@ BC="$B --workload clip"
 BS="$B --workload step"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 $BC > "$out/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -- python3 $BC > "$out/write.log" 2>&1
+# same two passes on the online path: 4-frame launches over 1024 streams only (tools/step_traffic_pass.py)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch_step" -- python3 "$R/tools/step_traffic_pass.py" > "$out/fetch_step.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write_step" -- python3 "$R/tools/step_traffic_pass.py" > "$out/write_step.log" 2>&1
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 GRBM_GUI_ACTIVE"
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$out/sq" -- python3 $BC > "$out/sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$out/sq_step" -- python3 $BS > "$out/sq_step.log" 2>&1

@@ -76,6 +76,29 @@ def main(tag):
         rd, wr = fa * 1024 * cal / 1e6, wa * 1024 / 1e6
         traffic[k] = dict(launches=max(len(f), len(w)), fetch_raw_kib=fa, write_raw_kib=wa, read_MB=rd, write_MB=wr)
         lines.append(f"| {k} | {max(len(f), len(w))} | {fa:.1f} | {wa:.1f} | {rd:.2f} | {wr:.2f} |")
+    # online path (tools/step_traffic_pass.py: 4-frame launches over all 1024 streams, the launch shape of bench.py's
+    # kernel-timing pass): same counters, same calibration factor.  Launches of the first cycles, in which the
+    # strided blocks emit less than in steady state, have smaller grids and are left out.
+    def pmc_largest_grid(sub, counter):
+        rows = collections.defaultdict(list)
+        for r in rows_of(f"{d}/{sub}/**/*counter_collection.csv"):
+            if r["Counter_Name"] == counter:
+                rows[short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+        return {k: [v for g, v in rs if g == max(g2 for g2, _ in rs)] for k, rs in rows.items()}
+    fetch_s, write_s = pmc_largest_grid("fetch_step", "FETCH_SIZE"), pmc_largest_grid("write_step", "WRITE_SIZE")
+    step_traffic = {}
+    if fetch_s or write_s:
+        lines += ["", "## HBM traffic per launch, online workload (PMC passes of `tools/step_traffic_pass.py`: 4-frame launches over all 1024 streams = the launch shape of the kernel-timing pass)", "",
+                  "| kernel | launches | FETCH_SIZE raw avg KiB | WRITE_SIZE raw avg KiB | HBM read MB (calibrated) | HBM write MB |", "|---|---|---|---|---|---|"]
+        for k in sorted(set(fetch_s) | set(write_s)):
+            if "step_kernel" not in k and "gcn_stage" not in k:
+                continue
+            f, w = fetch_s.get(k, []), write_s.get(k, [])
+            fa = sum(f) / len(f) if f else 0.0
+            wa = sum(w) / len(w) if w else 0.0
+            rd, wr = fa * 1024 * cal / 1e6, wa * 1024 / 1e6
+            step_traffic[k] = dict(launches=max(len(f), len(w)), fetch_raw_kib=fa, write_raw_kib=wa, read_MB=rd, write_MB=wr)
+            lines.append(f"| {k} | {max(len(f), len(w))} | {fa:.1f} | {wa:.1f} | {rd:.2f} | {wr:.2f} |")
     lines += ["", "## SQ counters per kernel (sum over launches)", "",
               "| kernel | clock GHz | MFMA busy frac | waves/SIMD | WAIT_ANY/wave | WAIT_INST/wave |", "|---|---|---|---|---|---|"]
     durs = collections.defaultdict(float)
@@ -106,6 +129,15 @@ def main(tag):
         hb = sum((v["read_MB"] + v["write_MB"]) * 1e6 * v["launches"] for v in dom) / n
         json.dump({"kernel": "tcn_stage_kernel", "hbm_bytes_per_launch": hb, "launches": n, "source": f"profiles/{tag}_traffic.json",
                    "batch": 256}, open(os.path.join(ROOT, "profiles", "traffic_tcn_stage.json"), "w"), indent=1)
+    dom = [v for k, v in step_traffic.items() if k.startswith("tcn_step_kernel")]
+    if dom:
+        n = sum(v["launches"] for v in dom)
+        hb = sum((v["read_MB"] + v["write_MB"]) * 1e6 * v["launches"] for v in dom) / n
+        json.dump({"kernel": "tcn_step_kernel", "hbm_bytes_per_launch": hb, "launches": n, "source": f"profiles/{tag}_traffic.json",
+                   "streams": 1024, "stream_shards": 1, "frames_per_launch": 4},
+                  open(os.path.join(ROOT, "profiles", "traffic_tcn_step.json"), "w"), indent=1)
+    traffic.update({"step:" + k: v for k, v in step_traffic.items()})
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
