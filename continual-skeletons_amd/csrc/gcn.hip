@@ -21,6 +21,7 @@ struct GcnParams {
     int dense;   // src[e] == e for all subsets and columns (checked on the host side of the ABI by construction)
     int adj_per_frame;   // the (dense) adjacency varies per FRAME of a segment: index = seg * frames + frame
     int lds_frames;      // frames of adjacency staged per workgroup in that mode
+    unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup of the sparse kernel
 };
 
 template <int MT, int NJ>
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
     const int qend = min(q0 + NT, Q);
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
     const int span = (tb - ta + 1) * V;
-
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, ph0 = 0, ph1 = 0, ph2 = 0, tq = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
     // per-lane adjacency entries of the two output columns this lane feeds (B operand: column = lane & 31)
     int eoff[2][6];
     float eval[2][6];
@@ -318,19 +320,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
     issue_w(0);
     issue_x(0);
     int c0 = 0;
+    if (p.stamps) tq = st1 = __builtin_amdgcn_s_memtime();
     for (; c0 + KCG < cpad; c0 += KCG) {
         __syncthreads();
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
         commit();
         __syncthreads();
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
         issue_w(c0 + KCG);                                 // next chunk's loads fly underneath the MFMAs
         issue_x(c0 + KCG);
         __builtin_amdgcn_s_setprio(1);
         mfma_steps(0, KCG / 2);
         __builtin_amdgcn_s_setprio(0);
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
     }
     __syncthreads();                                       // peeled last chunk: the staging registers are dead,
     commit();                                              // so the epilogue operands are loaded under its MFMAs
     __syncthreads();
+    if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
     float bb[2][16], rv[2][2][16];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -348,6 +355,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
             }
     }
     mfma_steps(0, KCG / 2);
+    unsigned long long st3 = 0;
+    if (p.stamps) st3 = __builtin_amdgcn_s_memtime();
 
     // epilogue: ReLU(acc + bias + identity residual); permlane32_swap pairs the ni = 0/1 registers so that every
     // store instruction writes one 256-B contiguous row segment (see tcn_stage_kernel)
@@ -365,6 +374,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
             if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = __uint_as_float(sw[0]);
             if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = __uint_as_float(sw[1]);
         }
+    if (p.stamps && lane == 0) {   // [wg][wave][8]: start, loop start, last-chunk start, mfma end, end, wait/commit/mfma sums
+        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memtime(); o[5] = ph0; o[6] = ph1; o[7] = ph2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,6 +418,7 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     // per-segment adjacencies are dense by contract (include/cskel.h): ell_w == V, ell_cnt == {V,V,V}, src[e] == e
     p.dense = adj_seg_stride != 0 && ell_w == V && ell_cnt[0] == V && ell_cnt[1] == V && ell_cnt[2] == V;
     p.adj_per_frame = adj_per_frame != 0;
+    p.stamps = csk_diag_stamps();
     if (p.adj_per_frame && !p.dense) CSK_FAIL("gcn_stage: per-frame adjacency must be dense (ell_w == V, ell_cnt == V)");
     p.vmagic = vmagic_of(V);
     const bool big = (p.Mpad % 128) == 0;
