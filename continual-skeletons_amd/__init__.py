@@ -26,7 +26,8 @@ from .continual import (  # noqa: F401
     CoTemporalConvolution,
 )
 from .agcn import AdaptiveGraphConvolution, AGcn, CoAdaptiveGraphConvolution, CoAGcn  # noqa: F401
-from . import fusion, native  # noqa: F401
+from . import fusion, native, weights  # noqa: F401
+from .weights import load_pretrained  # noqa: F401
 
 # names used by BASELINE.json:north_star
 SpatialGraphConv = GraphConvolution

@@ -325,13 +325,20 @@ class CoStGcn(_Folded):
 
     # ---- weights ---------------------------------------------------------------------------------
     def map_state_dict(self, state_dict, strict=True):
-        """Regular-layout keys -> this module's (reference Co) layout (models/base.py:200-224)."""
+        """Regular-layout keys -> this module's (reference Co) layout (models/base.py:200-224).  A state dict
+        that already holds every key of this module is returned unchanged, as in the reference."""
         own = nn.Module.state_dict(self).keys()
+        if not (own - state_dict.keys()):
+            return state_dict
 
         def short(k):
             return k.replace("0.1.", "").replace("0.0.residual", "residual")
         short2long = {short(k): k for k in own}
         return OrderedDict((short2long[k], v) for k, v in state_dict.items() if strict or k in short2long)
+
+    def map_loaded_weights(self, file, loaded_state_dict):
+        """Hook called by the checkpoint loader (models/base.py:226-227; weights.load_pretrained here)."""
+        return self.map_state_dict(loaded_state_dict)
 
     def _fold(self):
         s, t = fold.fold_data_bn({k: v for k, v in nn.Module.state_dict(self).items() if k.startswith("data_bn.")})

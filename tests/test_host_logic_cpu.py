@@ -75,6 +75,40 @@ def test_costgcn_keys_and_map_state_dict():
     assert (co.receptive_field, co.padding, co.stride, co.pool_size, co.pool_padding) == (153, 76, 4, 75, 19)
 
 
+def test_load_pretrained_pt_and_ckpt(tmp_path):
+    """Weight import path: a regular ST-GCN state dict saved as .pt, or inside a Lightning-style
+    .ckpt, loads into StGcn and -- through map_loaded_weights (models/base.py:226-227) -- into CoStGcn; a state
+    dict already in the continual layout passes through unchanged; junk files are refused."""
+    import torch
+    A = pkg.ntu_graph().A
+    src = pkg.StGcn(A)
+    with torch.no_grad():
+        for prm in src.parameters():
+            prm.add_(0.01)
+    pt, ckpt, junk = tmp_path / "w.pt", tmp_path / "w.ckpt", tmp_path / "junk.pt"
+    torch.save(src.state_dict(), pt)
+    torch.save({"state_dict": src.state_dict(), "epoch": 3}, ckpt)
+    torch.save([1, 2, 3], junk)
+    reg, co = pkg.StGcn(A), pkg.CoStGcn(A)
+    pkg.load_pretrained(reg, str(pt))
+    pkg.load_pretrained(co, str(ckpt))
+    want = src.state_dict()
+    assert all(torch.equal(v, want[k]) for k, v in reg.state_dict().items())
+    short = lambda k: k.replace("0.1.", "").replace("0.0.residual", "residual")  # noqa: E731
+    assert all(torch.equal(v, want[short(k)]) for k, v in co.state_dict().items())
+    assert co.map_loaded_weights(str(pt), co.state_dict()) is not None
+    same = co.state_dict()
+    assert co.map_state_dict(same) is same                      # already in the continual layout: unchanged
+    extra = dict(src.state_dict(), not_a_key=torch.zeros(1))
+    torch.save(extra, pt)
+    with pytest.raises((RuntimeError, KeyError)):
+        pkg.load_pretrained(pkg.CoStGcn(A), str(pt))            # strict: unexpected key
+    res = pkg.load_pretrained(pkg.CoStGcn(A), str(pt), strict=False)
+    assert not res.missing_keys
+    with pytest.raises(RuntimeError, match="not a state dict"):
+        pkg.load_pretrained(reg, str(junk))
+
+
 def test_fold_reproduces_oracle_pointwise():
     """Evaluate the PACKED operands with plain numpy (test-only) and compare with the oracle."""
     a, sd = load_golden("g3_block_strided")
