@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void loop_kernel(float *out, int chunks) {
 // STRUCT variants: the plain loop plus, cumulatively, the per-chunk structure of tcn_stage_kernel
 //   level 1: two __syncthreads per chunk      level 2: + commit of 9 f32x4 + 18 dwords per thread to LDS
 //   level 3: + 27 global loads per thread per chunk (next chunk's operands, register prefetch), three bursts
-template <int LEVEL>
-__global__ __launch_bounds__(256, 2) void struct_kernel(float *out, const float *gw, const float *gb, int chunks) {
+template <int LEVEL, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void struct_kernel(float *out, const float *gw, const float *gb, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem, *Bl = smem + TAPS * KC * MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
@@ -151,17 +151,17 @@ __global__ __launch_bounds__(256, 2) void struct_kernel(float *out, const float 
     out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int L> double run_struct(int chunks, int blocks) {
+template <int L, int OCC = 2> double run_struct(int chunks, int blocks) {
     float *out, *gw, *gb;
     hipMalloc(&out, (size_t)blocks * 256 * 4);
     hipMalloc(&gw, (size_t)32 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)32 * 9216 * 4 + 65536);
     hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
     const size_t lds = (TAPS * KC * MT + KC * LDB) * 4;
-    hipFuncSetAttribute((const void *)struct_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)struct_kernel<L, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(struct_kernel<L>, dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((struct_kernel<L, OCC>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
     hipEventRecord(e0);
-    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(struct_kernel<L>, dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((struct_kernel<L, OCC>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     hipFree(out); hipFree(gw); hipFree(gb);
@@ -193,5 +193,9 @@ int main() {
     printf("struct 1 (+ 2 barriers per chunk):                      %.1f TFLOP/s\n", run_struct<1>(chunks, blocks));
     printf("struct 2 (+ LDS commit of 9 f32x4 + 18 dwords):         %.1f TFLOP/s\n", run_struct<2>(chunks, blocks));
     printf("struct 3 (+ 27 global prefetch loads in 3 bursts):      %.1f TFLOP/s\n", run_struct<3>(chunks, blocks));
+    // the same structure with three workgroups per CU (3 waves/SIMD, <= 168 VGPRs, 3 x 48.9 KB LDS)
+    printf("struct 0 at 3 workgroups/CU:                            %.1f TFLOP/s\n", run_struct<0, 3>(chunks, 768 * 4));
+    printf("struct 3 at 3 workgroups/CU:                            %.1f TFLOP/s\n", run_struct<3, 3>(chunks, 768 * 4));
+    printf("struct 3 at 2 workgroups/CU, same grid:                 %.1f TFLOP/s\n", run_struct<3, 2>(chunks, 768 * 4));
     return 0;
 }
