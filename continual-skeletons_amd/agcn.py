@@ -45,10 +45,11 @@ class AdaptiveGraphConvolution(GraphConvolution):
         f["b_embed"] = fold.pad_vec(be.double())
         return f
 
-    def _attention(self, E, ops, n_seg, T, V, e_seg_stride, e_chan_stride):
+    def _attention(self, E, ops, n_seg, T, V, e_seg_stride, e_chan_stride, seg_per_group=None, e_group_stride=0):
         adj = torch.empty((n_seg, 3, V, V), device=E.device, dtype=torch.float32)
         rc = native.lib().csk_agcn_attention_f32(native.ptr(E), native.ptr(ops["a_sum"]), native.ptr(adj), n_seg,
-                                                 self.inter_c, T, V, e_seg_stride, e_chan_stride, native.stream_of(E))
+                                                 self.inter_c, T, V, e_seg_stride, e_chan_stride,
+                                                 seg_per_group or n_seg, e_group_stride, native.stream_of(E))
         native.check(rc, "csk_agcn_attention_f32")
         return adj
 
@@ -68,25 +69,23 @@ class AdaptiveGraphConvolution(GraphConvolution):
 
     def stage(self, x, y, n_seg, frames, x_strides, y_strides):
         """Continual use on channel-major frames (C, P): every skeleton is its own 'sample' with T = 1, so the
-        attention is computed per skeleton (coa_gcn.py: forward_stepping of the module) and the graph conv runs
-        with a per-frame adjacency.  n_seg ring slots are handled one by one."""
+        attention is computed per skeleton and frame (coa_gcn.py: forward_stepping of the module) and the graph
+        conv runs with a per-frame adjacency.  The n_seg consecutive ring slots of a launch cycle go through three
+        launches together: embedding conv (one emission per slot), attention, graph conv (one segment per slot)."""
         ops = self._packed_ops(x.device)
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
-        for j in range(n_seg):
-            # slot j of the ring the views x / y point into (consecutive slots, stride = one frame)
-            xf = torch.as_strided(x, x.shape, x.stride(), x.storage_offset() + j * x_strides[0])
-            yf = torch.as_strided(y, y.shape, y.stride(), y.storage_offset() + j * y_strides[0])
-            E = torch.empty((e_ch, p), device=x.device, dtype=torch.float32)
-            rc = native.lib().csk_tcn_step_f32(native.ptr(xf), 1, 0, 0, 1, native.ptr(ops["w_embed"]), None, 0, 0, 0, None,
-                                               native.ptr(ops["b_embed"]), native.ptr(E), 1, 0, self.in_channels, e_ch, p,
-                                               1, 0, 0, 0, native.stream_of(x))
-            native.check(rc, "csk_tcn_step_f32")
-            adj = self._attention(E, ops, frames, 1, v, v, p)
-            o = dict(ops, ell_val=adj)
-            # one launch over all skeletons: segment = the whole channel-major frame, adjacency per "frame" (skeleton)
-            blocks.gcn_stage(xf, yf, o, n_seg=1, frames=frames, x_strides=(0, p), y_strides=(0, p),
-                             adj_seg_stride=3 * v * v, adj_per_frame=1)
+        E = torch.empty((n_seg, e_ch, p), device=x.device, dtype=torch.float32)
+        # k = 1 "temporal" conv over a ring of n_seg slots = the block-input slots themselves: emission j reads slot j
+        rc = native.lib().csk_tcn_step_f32(native.ptr(x), n_seg, 0, 1, n_seg, native.ptr(ops["w_embed"]), None, 0, 0, 0, None,
+                                           native.ptr(ops["b_embed"]), native.ptr(E), n_seg, 0, self.in_channels, e_ch, p,
+                                           1, 0, 0, 0, native.stream_of(x))
+        native.check(rc, "csk_tcn_step_f32")
+        adj = self._attention(E, ops, n_seg * frames, 1, v, v, p, seg_per_group=frames, e_group_stride=e_ch * p)
+        o = dict(ops, ell_val=adj)
+        # segment = one channel-major frame, adjacency per "frame" of it (= skeleton): index seg * frames + skeleton
+        blocks.gcn_stage(x, y, o, n_seg=n_seg, frames=frames, x_strides=x_strides, y_strides=y_strides,
+                         adj_seg_stride=3 * v * v, adj_per_frame=1)
 
 
 def CoAdaptiveGraphConvolution(in_channels, out_channels, A, bn_momentum=0.1):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 4
+#define CSK_ABI_VERSION 5
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -130,13 +130,17 @@ int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *l
  * A-GCN adaptive adjacency, models/a_gcn/a_gcn.py:53-63.  E holds the a_conv / b_conv embeddings of the three
  * subsets (channels [i*inter+k] = a_conv_i, [(3+i)*inter+k] = b_conv_i, biases included; a 1x1 conv produced by
  * csk_tcn_stage_f32 (clip) or csk_tcn_step_f32 (continual)); element (n, ch, t, v) at
- * n*e_seg_stride + ch*e_chan_stride + t*V + v.  For every sample and subset:
+ * (n / seg_per_group)*e_group_stride + (n % seg_per_group)*e_seg_stride + ch*e_chan_stride + t*V + v
+ * (clip: seg_per_group = n_seg, e_group_stride = 0; continual: a group = one channel-major frame (6*inter, P) of
+ * the frames of a launch cycle, a segment = one skeleton of it, e_seg_stride = V, T = 1 -- per-frame attention,
+ * models/coa_gcn/coa_gcn.py:11-14).  For every sample and subset:
  *     adj[i][v, w] = softmax_v( sum_{k,t} Ea[k,t,v] * Eb[k,t,w] / (inter*T) ) + a_sum[i][v, w],   a_sum = A + graph_attn
  * written as the dense column-wise ELL values ell_val[n][i][w][v] that csk_gcn_stage_f32 consumes with
  * ell_w = V, ell_cnt = {V,V,V}, adj_seg_stride = 3*V*V.
  */
 int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, int n_seg, int inter, int T, int V,
-                           int64_t e_seg_stride, int64_t e_chan_stride, void *stream);
+                           int64_t e_seg_stride, int64_t e_chan_stride, int seg_per_group, int64_t e_group_stride,
+                           void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Continual (frame-by-frame) path.  The arithmetic the reference delegates to the third-party package
