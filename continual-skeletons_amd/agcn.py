@@ -43,6 +43,14 @@ class AdaptiveGraphConvolution(GraphConvolution):
         be = torch.cat([sd[f"a_conv.{i}.bias"] for i in range(3)] + [sd[f"b_conv.{i}.bias"] for i in range(3)], 0)
         f["w_embed"] = fold.pack_conv_weight(we.view(6 * inter, ci, 1, 1), torch.ones(6 * inter, dtype=torch.float64))
         f["b_embed"] = fold.pad_vec(be.double())
+        # Continual use: a 1x1 conv has one "tap", i.e. 16 MFMAs per barrier pair of the step kernel.  The channel
+        # axis is therefore cut into g groups that are presented to the kernel as the g taps of a (g x 1) conv over
+        # C_in / g channels -- group r of a channel-major frame (C_in, P) *is* ring slot r of a ring of (C_in / g, P)
+        # frames -- which gives g times longer MFMA runs per chunk.  Same sums, different summation order.
+        g = next(k for k in (8, 4, 2, 1) if ci % (fold.KC * k) == 0 or k == 1)
+        f["embed_groups_host"] = torch.tensor([g], dtype=torch.int32)
+        wg = we.view(6 * inter, g, ci // g).permute(0, 2, 1).unsqueeze(-1)                    # (co, C_in / g, g, 1)
+        f["w_embed_step"] = fold.pack_conv_weight(wg.contiguous(), torch.ones(6 * inter, dtype=torch.float64))
         return f
 
     def _attention(self, E, ops, n_seg, T, V, e_seg_stride, e_chan_stride, seg_per_group=None, e_group_stride=0):
@@ -76,10 +84,12 @@ class AdaptiveGraphConvolution(GraphConvolution):
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
         E = torch.empty((n_seg, e_ch, p), device=x.device, dtype=torch.float32)
-        # k = 1 "temporal" conv over a ring of n_seg slots = the block-input slots themselves: emission j reads slot j
-        rc = native.lib().csk_tcn_step_f32(native.ptr(x), n_seg, 0, 1, n_seg, native.ptr(ops["w_embed"]), None, 0, 0, 0, None,
-                                           native.ptr(ops["b_embed"]), native.ptr(E), n_seg, 0, self.in_channels, e_ch, p,
-                                           1, 0, 0, 0, native.stream_of(x))
+        # the 1x1 embedding conv as a (g x 1) conv over channel groups (see _fold): the n_seg block-input slots are a
+        # ring of g * n_seg slots of (C_in / g, P); emission j reads slots g*j .. g*j + g - 1
+        g = int(ops["embed_groups_host"][0])
+        rc = native.lib().csk_tcn_step_f32(native.ptr(x), g * n_seg, g - 1, g, n_seg, native.ptr(ops["w_embed_step"]), None, 0, 0, 0,
+                                           None, native.ptr(ops["b_embed"]), native.ptr(E), n_seg, 0, self.in_channels // g, e_ch,
+                                           p, g, 0, 0, 0, native.stream_of(x))
         native.check(rc, "csk_tcn_step_f32")
         adj = self._attention(E, ops, n_seg * frames, 1, v, v, p, seg_per_group=frames, e_group_stride=e_ch * p)
         o = dict(ops, ell_val=adj)
