@@ -23,14 +23,18 @@ for name, cls in (("ST-GCN", pkg.StGcn), ("AGCN", pkg.AGcn)):
     dt = timeit(lambda: net(x), 5)
     print(f"{name:8s} clip batch 64 Kinetics shape: {dt*1e3:8.2f} ms/step  {64/dt:8.1f} clips/s")
     del net
-streams = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+shards = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+from continual_skeletons_amd import parallel
 frames = torch.rand((8, streams, 3, 18, 2), device=dev)
 for name, cls in (("CoST-GCN", pkg.CoStGcn), ("CoAGCN", pkg.CoAGcn)):
-    net = cls(A, shape, 400).eval(); bench.randomise_(net, 0); net = net.to(dev)
-    for t in range(80): net.forward_cycle([frames[t % 8]])
+    def make():
+        net = cls(A, shape, 400).eval(); bench.randomise_(net, 0); return net.to(dev)
+    eng = parallel.StreamShards(make, streams, shards, dev)
+    for t in range(80): eng.forward_cycle([frames[t % 8]])
     i = [0]
     def cyc():
-        net.forward_cycle([frames[(i[0] + f) % 8] for f in range(4)]); i[0] += 4
-    dt = timeit(cyc, 6)
-    print(f"{name:8s} online {streams} streams Kinetics shape: {dt/4*1e3:8.3f} ms/frame-step  {4*streams/dt:10.0f} frames/s")
-    del net
+        eng.forward_cycle([frames[(i[0] + f) % 8] for f in range(4)]); i[0] += 4
+    dt = timeit(cyc, 12)
+    print(f"{name:8s} online {streams} streams ({shards} shards) Kinetics shape: {dt/4*1e3:8.3f} ms/frame-step  {4*streams/dt:10.0f} frames/s")
+    del eng
