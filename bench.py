@@ -80,7 +80,7 @@ class LaunchTimer:
 def tcn_flops_per_clip_forward(nm, c_in=3, T=300, V=25):
     """Algorithmic FLOPs of the ten tcn_stage launches for nm skeleton sequences (TCN 9x1 +
     block-residual 1x1 MACs, 2 FLOP per MAC)."""
-    from oracle.stgcn_oracle import layer_table
+    from continual_skeletons_amd.models import layer_table
     t, macs = T, 0
     for (ci, co, s, res) in layer_table(c_in):
         t_out = (t + 8 - 9) // s + 1
@@ -114,7 +114,7 @@ def cpu_baseline_clip(seed, threads):
 def step_flops_per_cycle(nm, c_in=3, V=25):
     """Algorithmic FLOPs of one 4-frame stride cycle of the ten continual blocks for nm skeletons (SURVEY 8d:
     28.75 MMAC per skeleton-frame, frame-rate weighted): (gcn_flops, tcn_flops)."""
-    from oracle.stgcn_oracle import layer_table
+    from continual_skeletons_amd.models import layer_table
     rate, g, t = 4, 0, 0            # frames per 4-frame cycle entering the block
     for (ci, co, s, res) in layer_table(c_in):
         r = 4 if ci != co else 3

@@ -4,8 +4,9 @@ x ~ x_hi + x_lo (+ x_lo2), each bf16; products of bf16 values are exact in fp32,
 rounded pieces in fp32 emulates bf16 MFMA with fp32 accumulation.  Schemes: 3 products (hh, hl, lh) and
 6 products (3-way split: hh, hm, mh, hl, lh, mm)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests", "golden"))
 import torch, torch.nn.functional as F
 _conv2d = F.conv2d       # the real one (the oracle's F.conv2d is patched below)
 from oracle import stgcn_oracle as o

@@ -148,6 +148,32 @@ def test_product_never_imports_oracle():
             assert not any(m.split(".")[0] == "oracle" for m in mods), f"{fn} imports the oracle"
 
 
+def _oracle_imports(path):
+    """(enclosing top-level function or None, module) for every import of the oracle in a source file."""
+    import ast
+    tree = ast.parse(open(path).read())
+    found = []
+    for top in tree.body:
+        owner = top.name if isinstance(top, (ast.FunctionDef, ast.ClassDef)) else None
+        for node in ast.walk(top):
+            mods = [a.name for a in node.names] if isinstance(node, ast.Import) else \
+                   [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+            found += [(owner, m) for m in mods if m.split(".")[0] == "oracle"]
+    return found
+
+
+def test_oracle_is_only_used_as_checker_or_cpu_baseline():
+    """Outside tests/ the oracle may be touched by bench.py's cpu_baseline leg and __graft_entry__.smoke() only;
+    the tools never use it."""
+    assert {o for o, _ in _oracle_imports(os.path.join(ROOT, "bench.py"))} <= {"cpu_baseline_clip", "cpu_baseline_step"}
+    assert {o for o, _ in _oracle_imports(os.path.join(ROOT, "__graft_entry__.py"))} <= {"smoke", "build"}
+    tools = os.path.join(ROOT, "tools")
+    for fn in os.listdir(tools):
+        if fn.endswith(".py"):
+            assert not _oracle_imports(os.path.join(tools, fn)), f"tools/{fn} imports the oracle"
+    assert not _oracle_imports(os.path.join(ROOT, "_bootstrap.py"))
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(pkg.native, "_lib", None)
     monkeypatch.setattr(pkg.native, "LIB_PATH", "/nonexistent/libcskel_hip.so")
