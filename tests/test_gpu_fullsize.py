@@ -74,3 +74,84 @@ def test_config3_1024_streams_online():
     for gv, sv in zip(got, got_small):
         assert torch.equal(gv[sel], sv)
     assert 4.0 < big.state_bytes() / 1e9 < 12.0      # 16-slot rings for 1024 streams: ~9.2 GB of 288 GB
+
+
+def _randomise_agcn(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("graph_attn") or ("bn" in name and name.endswith("weight")):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand(prm.shape, generator=g) - 0.5)
+            elif "a_conv" in name or "b_conv" in name:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.5)       # a non-uniform attention
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
+
+
+def test_config4_agcn_clip_batch64_kinetics_shape():
+    """BASELINE configs[3], clip form: A-GCN (per-sample adaptive adjacency), Kinetics-400 shape (V = 18, T = 300),
+    batch 64: logits of a 2-clip slice vs the oracle; the attention is per sample, so rows of the full batch must
+    equal -- bit for bit -- the same clips run in batches of 16."""
+    Ak = pkg.kinetics_graph().A
+    net = pkg.AGcn(Ak, input_shape=(3, 300, 18, 2), num_classes=400).eval()
+    _randomise_agcn(net, 21)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    x = torch.rand((64, 3, 300, 18, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    full = net(x)
+    assert full.shape == (64, 400) and bool(torch.isfinite(full).all())
+    idx = [0, 63]
+    with torch.no_grad():
+        want = o.stgcn_forward(x[idx].cpu(), sd, gcn=o.adaptive_graph_conv)
+    assert max_err(full[idx].cpu(), want) <= TOL * max(1.0, float(want.abs().max()))
+    for lo in range(0, 64, 16):
+        assert torch.equal(net(x[lo:lo + 16].contiguous()), full[lo:lo + 16])
+
+
+def test_config4_coagcn_1024_streams_kinetics_shape():
+    """BASELINE configs[3], online form: CoAGCN (per-frame attention) with 1024 concurrent streams, V = 18:
+    predictions of 2 streams vs the oracle stepping them alone, and stream invariance (bitwise) against a
+    3-stream slab driven frame by frame (the big slab runs 4-frame launch cycles)."""
+    Ak = pkg.kinetics_graph().A
+    T = 76 + 4 * 4 + 1
+
+    def make():
+        net = pkg.CoAGcn(Ak, input_shape=(3, 300, 18, 2), num_classes=400, pool_size=3, pool_padding=1).eval()
+        _randomise_agcn(net, 22)
+        return net
+    big = make()
+    sd = {k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in big.state_dict().items()}
+    big = big.to(DEV)
+    frames = torch.rand((T, 1024, 3, 18, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    got, t = [], 0
+    while t < T:
+        r = min(4, T - t)
+        got += big.forward_cycle([frames[t + f] for f in range(r)])
+        t += r
+    assert len(got) >= 3 and all(gv.shape == (1024, 400) for gv in got)
+    pick = [7, 1001]
+    orc = o.CoStGcnOracle(sd, pool_size=3, pool_padding=1)
+    for b in orc.blocks:
+        b.gcn = o.adaptive_graph_conv
+    want = []
+    with torch.no_grad():
+        for t in range(T):
+            r = orc.forward_step(frames[t][pick].cpu())
+            if r is not None:
+                want.append(r)
+    assert len(want) == len(got)
+    for gv, wv in zip(got, want):
+        assert max_err(gv[pick].cpu(), wv) <= TOL * max(1.0, float(wv.abs().max()))
+    small = make()
+    small.load_state_dict(big.state_dict(), strict=True)       # make() draws fresh conv weights
+    small = small.to(DEV)
+    sel = [7, 8, 1001]
+    got_small = [r for r in (small.forward_step(frames[t][sel].contiguous()) for t in range(T)) if r is not None]
+    assert len(got_small) == len(got)
+    for gv, sv in zip(got, got_small):
+        assert torch.equal(gv[sel], sv)
