@@ -155,3 +155,18 @@ def test_config4_coagcn_1024_streams_kinetics_shape():
     assert len(got_small) == len(got)
     for gv, sv in zip(got, got_small):
         assert torch.equal(gv[sel], sv)
+
+
+def test_config5_per_gpu_shard_of_1024_clips():
+    """BASELINE configs[4] shards 8192 clips over 8 GPUs: one rank's 1024-clip shard in a single forward (3.9 GB
+    activations per 64-channel layer) must reproduce, bit for bit, the same clips run 256 at a time, which is what
+    makes the all-gathered logits independent of the world size (tests/test_parallel_cpu.py covers the gather)."""
+    a, sd, _ = g6_state_dict("ntu")
+    net = pkg.StGcn(A).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    x = torch.rand((1024, 3, 300, 25, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    full = net(x)
+    assert full.shape == (1024, 60) and bool(torch.isfinite(full).all())
+    for lo in (0, 768):
+        assert torch.equal(net(x[lo:lo + 256].contiguous()), full[lo:lo + 256])
