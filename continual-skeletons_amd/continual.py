@@ -168,8 +168,10 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         self._state: Optional[_BlockState] = None
         self._register_state_dict_hook(CoSpatioTemporalBlock._to_co_keys)
         self._register_load_state_dict_pre_hook(self._from_co_keys)
-        if not (isinstance(self.gcn, GraphConvolution) and self._native_tail):
-            raise NotImplementedError("continual blocks need the native GraphConvolution / TemporalConvolution")
+        if not self._native_tail:
+            raise NotImplementedError("continual blocks need the native TemporalConvolution (the ring-buffer step kernel)")
+        # self.gcn may be any per-frame graph-conv module (models/base.py:273-276 applies it frame by frame): native
+        # ones bring a ``stage`` method on the channel-major state layout, foreign ones go through _foreign_gcn_stage
 
     # ---- state_dict key layout -------------------------------------------------------------------
     @staticmethod
@@ -218,9 +220,11 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             run = min(r - f, HIST - s % HIST, YRING - s % YRING)
             if flush:
                 st.y[s % YRING: s % YRING + run].zero_()
-            else:
+            elif hasattr(self.gcn, "stage"):
                 self.gcn.stage(st.xin[s % HIST], st.y[s % YRING], n_seg=run, frames=n_frames,
                                x_strides=(self.in_channels * p, p), y_strides=(self.out_channels * p, p))
+            else:
+                self._foreign_gcn_stage(st, s, run, n_frames, V)
             f += run
         first = next((s for s in range(s0, s0 + r) if s >= self.delay and (s - self.delay) % self.stride == 0), None)
         st.s += r
@@ -239,6 +243,20 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             native.stream_of(st.y))
         st.e += n_emit
         return slot0, n_emit
+
+    def _foreign_gcn_stage(self, st, s: int, run: int, n_frames: int, V: int):
+        """Graph-conv modules without a native ``stage`` (e.g. the S-TR spatial attention a sibling model passes as
+        ``CoGraphConv``, models/base.py:390-400): applied per frame as ``module(x_t.unsqueeze(2)).squeeze(2)``
+        (base.py:273-276) on (NM, C, 1, V) tensors converted from / to the channel-major ring slots."""
+        q = n_frames * V
+        for j in range(run):
+            xs, ys = st.xin[(s + j) % HIST], st.y[(s + j) % YRING]
+            x_t = xs[:, :q].reshape(self.in_channels, n_frames, V).permute(1, 0, 2).unsqueeze(2).contiguous()
+            y_t = self.gcn(x_t)
+            if tuple(y_t.shape) != (n_frames, self.out_channels, 1, V) or y_t.dtype != torch.float32 or y_t.device != xs.device:
+                raise RuntimeError(f"graph-conv module returned {tuple(y_t.shape)} {y_t.dtype} on {y_t.device}, expected "
+                                   f"{(n_frames, self.out_channels, 1, V)} float32 on {xs.device}")
+            ys[:, :q] = y_t.squeeze(2).permute(1, 0, 2).reshape(self.out_channels, q)
 
     def engine_step(self, n_frames: int, V: int, flush: bool = False) -> Optional[int]:
         """One frame; returns the output-ring slot of this step's emission or None."""

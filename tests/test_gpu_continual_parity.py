@@ -191,3 +191,44 @@ def test_native_plan_equals_python_engine_and_survives_weight_reload():
         outs[native_plan] = got
     assert len(outs[True]) == len(outs[False]) >= 10
     assert all(torch.equal(p, q) for p, q in zip(outs[True], outs[False]))
+
+
+class _ForeignGraphConv(torch.nn.Module):
+    """A graph conv the package knows nothing about (stands for the spatial-attention module S-TR passes as
+    ``GraphConv`` / ``CoGraphConv``, models/base.py:338-349,390-400): plain PyTorch ops, no ``stage`` method."""
+
+    def __init__(self, in_channels, out_channels, A, bn_momentum=0.1):
+        super().__init__()
+        self.mix = torch.nn.Conv2d(in_channels, out_channels, 1)
+        self.register_buffer("A", torch.as_tensor(A, dtype=torch.float32).sum(0))
+
+    def forward(self, x):                                            # (N, C, T, V) -> (N, C_out, T, V)
+        return torch.relu(torch.matmul(self.mix(x), self.A))
+
+
+def _foreign_gcn_oracle(x, sd, p=""):                                # p = "<block prefix>gcn." as the oracle's block passes it
+    y = torch.nn.functional.conv2d(x, sd[p + "mix.weight"], sd[p + "mix.bias"])
+    return torch.relu(torch.matmul(y, sd[p + "A"]))
+
+
+@pytest.mark.parametrize("ci,co,stride", [(6, 6, 1), (4, 8, 2)])
+def test_blocks_accept_a_foreign_graph_conv_module(ci, co, stride):
+    """SURVEY 8b: the blocks take arbitrary graph-conv factories.  Clip: module output feeds the fused TCN stage;
+    continual: the module is applied per frame on tensors converted from / to the ring slots; both vs the oracle."""
+    torch.manual_seed(5)
+    blk = pkg.SpatioTemporalBlock(ci, co, A, stride=stride, GraphConv=_ForeignGraphConv).eval()
+    for name, buf in blk.named_buffers():
+        if name.endswith("running_var"):
+            buf.uniform_(0.5, 1.5)
+        elif name.endswith("running_mean"):
+            buf.uniform_(-0.5, 0.5)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.rand(3, ci, 21, 25)
+    with torch.no_grad():
+        want = o.st_block(x, sd, "", stride, True, gcn=_foreign_gcn_oracle)
+    got = blk.to(DEV)(x.to(DEV)).cpu()
+    assert got.shape == want.shape and max_err(got, want) <= TOL
+    co_blk = pkg.CoSpatioTemporalBlock(ci, co, A, stride=stride, padding=4, CoGraphConv=_ForeignGraphConv).eval()
+    co_blk.load_state_dict(sd, strict=True)
+    steps = co_blk.to(DEV).forward_steps(x.to(DEV), pad_end=True).cpu()
+    assert steps.shape == want.shape and max_err(steps, want) <= TOL
