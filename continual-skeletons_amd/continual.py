@@ -81,10 +81,10 @@ class CoTemporalConvolution(TemporalConvolution):
         return out[:, : n * v].view(-1, n, v).permute(1, 0, 2).contiguous()
 
     def forward_step(self, x_t, update_state=True):
+        """One frame.  ``update_state=False`` computes the step without advancing: the frame lands in the ring slot
+        of the frame that has just left the window, so putting the counter back is all there is to undo."""
         self._require_eval()
         native.require_device_f32(x_t, "CoTemporalConvolution frame")
-        if not update_state:
-            raise NotImplementedError("update_state=False is not supported on the persistent-state path")
         n, c, v = x_t.shape
         p = self._state(n, v, x_t.device)
         self._ring[self._s % self.kernel_size, :, : n * v] = x_t.permute(1, 0, 2).reshape(c, n * v)
@@ -92,11 +92,20 @@ class CoTemporalConvolution(TemporalConvolution):
         out = None
         if s >= self.delay and (s - self.delay) % self.stride == 0:
             out = self._emit(n, v, p)
-        self._s += 1
+        if update_state:
+            self._s += 1
         return out
 
     def forward_steps(self, x, pad_end=False, update_state=True):
         n, c, t, v = x.shape
+        if not update_state:                       # several frames overwrite live window slots: keep a copy
+            self._state(n, v, x.device)
+            keep = (self._ring.clone(), self._s)
+            try:
+                return self.forward_steps(x, pad_end, True)
+            finally:
+                self._ring.copy_(keep[0])
+                self._s = keep[1]
         outs = [o for o in (self.forward_step(x[:, :, i].contiguous()) for i in range(t)) if o is not None]
         if pad_end:
             p = self._state(n, v, x.device)
@@ -273,20 +282,29 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
     def forward_step(self, x_t, update_state=True):
         self._require_eval()
         native.require_device_f32(x_t, "CoSpatioTemporalBlock frame")
-        if not update_state:
-            raise NotImplementedError("update_state=False is not supported on the persistent-state path")
         n, c, v = x_t.shape
         if c != self.in_channels:
             raise RuntimeError(f"expected (N, {self.in_channels}, V) frame, got {tuple(x_t.shape)}")
         st = self._ensure_state(n, v, x_t.device)
+        keep = (st.s, st.e)
         st.xin[st.s % HIST, :, : n * v] = x_t.permute(1, 0, 2).reshape(c, n * v)
         slot = self.engine_step(n, v)
+        if not update_state:       # one step only touches ring slots that are older than every window: counters suffice
+            st.s, st.e = keep
         if slot is None:
             return None
         return st.out[slot, :, : n * v].view(self.out_channels, n, v).permute(1, 0, 2).contiguous()
 
     def forward_steps(self, x, pad_end=False, update_state=True):
         n, c, t, v = x.shape
+        if not update_state:                       # several frames overwrite live window slots: keep a copy
+            st = self._ensure_state(n, v, x.device)
+            keep = (st.y.clone(), st.out.clone(), st.xin.clone(), st.s, st.e)
+            try:
+                return self.forward_steps(x, pad_end, True)
+            finally:
+                st.y.copy_(keep[0]); st.out.copy_(keep[1]); st.xin.copy_(keep[2])
+                st.s, st.e = keep[3], keep[4]
         outs = [o for o in (self.forward_step(x[:, :, i].contiguous()) for i in range(t)) if o is not None]
         if pad_end:
             st = self._state
@@ -486,6 +504,37 @@ class CoStGcn(_Folded):
             return self._plan_cycle(frames)
         return self._python_cycle(frames)
 
+    # ---- update_state=False (base.py:183-190 hand the flag through to co.Sequential) -------------------
+    def _counters(self):
+        snap = dict(frames=self._frames, feats=self._feats,
+                    layers=[(b._state.s, b._state.e) for b in (self.layers[f"layer{i + 1}"] for i in range(10))])
+        if self.__dict__.get("_plan"):
+            buf = (ctypes.c_int64 * 22)()
+            native.check(native.lib().csk_co_plan_counters(self._plan, buf, 22, 0), "csk_co_plan_counters")
+            snap["plan"] = list(buf)
+        return snap
+
+    def _set_counters(self, snap):
+        self._frames, self._feats = snap["frames"], snap["feats"]
+        for i, (s_, e_) in enumerate(snap["layers"]):
+            st = self.layers[f"layer{i + 1}"]._state
+            st.s, st.e = s_, e_
+        if "plan" in snap and self.__dict__.get("_plan"):
+            buf = (ctypes.c_int64 * 22)(*snap["plan"])
+            native.check(native.lib().csk_co_plan_counters(self._plan, buf, 22, 1), "csk_co_plan_counters")
+
+    def _state_tensors(self):
+        ts = [self._xin0, self._pool_ring, self._pooled]
+        for i in range(10):
+            st = self.layers[f"layer{i + 1}"]._state
+            ts += [st.y, st.out]
+        return ts
+
+    def _ensure_bound(self, x_t):
+        native.require_device_f32(x_t, "CoStGcn frame")
+        if self._n != x_t.shape[0] or self._xin0.device != x_t.device:
+            self._bind(x_t.shape[0], x_t.device)
+
     def _plan_cycle(self, frames):
         if self._plan_keep[1] != self._weights_version():
             self._refresh_plan_weights(frames[0].device)
@@ -553,10 +602,19 @@ class CoStGcn(_Folded):
         return self._cycle([x_t])[0]
 
     def forward_step(self, x_t, update_state=True):
-        """CoModelBase.forward_step (base.py:183-185): logits (N, classes) on predicting steps, else None."""
-        if not update_state:
-            raise NotImplementedError("update_state=False is not supported on the persistent-state path")
-        outs = self._cycle([x_t])[2]
+        """CoModelBase.forward_step (base.py:183-185): logits (N, classes) on predicting steps, else None.
+        ``update_state=False`` computes the step without advancing: a single step only overwrites ring slots whose
+        content has left every window (and the oldest entry of the pooling window, which the next real step replaces
+        as well), so restoring the counters restores the state."""
+        if update_state:
+            outs = self._cycle([x_t])[2]
+            return outs[-1] if outs else None
+        self._ensure_bound(x_t)
+        snap = self._counters()
+        try:
+            outs = self._cycle([x_t])[2]
+        finally:
+            self._set_counters(snap)
         return outs[-1] if outs else None
 
     def forward_cycle(self, frames):
@@ -568,6 +626,15 @@ class CoStGcn(_Folded):
         """(N, C, T, V, M) -> (N, classes, n_predictions) (empty last dim if nothing was emitted)."""
         if pad_end:
             raise NotImplementedError("model-level pad_end is not used by the reference (base.py:177)")
+        if not update_state:                       # several frames overwrite live window slots: keep a copy of the slab
+            self._ensure_bound(x[:, :, 0].contiguous())
+            snap, keep = self._counters(), [t.clone() for t in self._state_tensors()]
+            try:
+                return self.forward_steps(x, False, True)
+            finally:
+                for t, k in zip(self._state_tensors(), keep):
+                    t.copy_(k)
+                self._set_counters(snap)
         outs = []
         for t in range(x.shape[2]):
             o = self.forward_step(x[:, :, t].contiguous())

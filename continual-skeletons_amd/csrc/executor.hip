@@ -68,6 +68,21 @@ extern "C" int csk_co_plan_update_weights(csk_co_plan *plan, int n_layers, const
     return 0;
 }
 
+extern "C" int csk_co_plan_counters(csk_co_plan *plan, int64_t *buf, int n, int set) {
+    if (!plan || !buf) CSK_FAIL("co_plan_counters: null pointer");
+    if (n != 2 + 2 * (int)plan->layers.size()) CSK_FAIL("co_plan_counters: expected %d values", 2 + 2 * (int)plan->layers.size());
+    if (set) {
+        for (int i = 0; i < n; ++i)
+            if (buf[i] < 0) CSK_FAIL("co_plan_counters: negative counter");
+        plan->frames = (long)buf[0]; plan->feats = (long)buf[1];
+        for (size_t i = 0; i < plan->cnt.size(); ++i) { plan->cnt[i].s = (long)buf[2 + 2 * i]; plan->cnt[i].e = (long)buf[3 + 2 * i]; }
+    } else {
+        buf[0] = plan->frames; buf[1] = plan->feats;
+        for (size_t i = 0; i < plan->cnt.size(); ++i) { buf[2 + 2 * i] = plan->cnt[i].s; buf[3 + 2 * i] = plan->cnt[i].e; }
+    }
+    return 0;
+}
+
 extern "C" void csk_co_plan_reset(csk_co_plan *plan) {
     if (!plan) return;
     for (auto &c : plan->cnt) c = BlockCounters();

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 # name -> argtypes; mirrors include/cskel.h line by line
@@ -33,6 +33,7 @@ SIGNATURES = {
     "csk_co_plan_destroy": [_p],
     "csk_co_plan_update_weights": [_p, _i, _p, _p, _p, _p, _p],
     "csk_co_plan_reset": [_p],
+    "csk_co_plan_counters": [_p, C.POINTER(C.c_int64), _i, _i],
     "csk_co_plan_cycle": [_p, _p, _i, _p, _p, _p, _p, _p],
 }
 RESTYPES = {"csk_co_plan_create": C.c_void_p, "csk_co_plan_destroy": None, "csk_co_plan_reset": None}

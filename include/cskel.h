@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 5
+#define CSK_ABI_VERSION 6
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -225,6 +225,10 @@ int csk_co_plan_update_weights(csk_co_plan *plan, int n_layers, const csk_co_lay
                                const float *bn_shift, const float *fc_w, const float *fc_b);
 /* forget all counters (the caller zeroes the slab): clean_state(), models/base.py:161-164 */
 void csk_co_plan_reset(csk_co_plan *plan);
+/* read (set = 0) or write (set = 1) the plan's counters: buf = {frames, features, then (received, emitted) per layer},
+ * n = 2 + 2*n_layers.  forward_step(x, update_state=False) (models/base.py:183-185) = read, cycle, write back: a
+ * step only overwrites ring slots whose content is older than any window, so the counters are the whole state. */
+int csk_co_plan_counters(csk_co_plan *plan, int64_t *buf, int n, int set);
 /* Advance by r = 1..CSK_CO_MAX_CYCLE frames, frames[i] = (N, C, V, M) device pointers.  On return
  * *last_slot / *n_feat describe the last layer's emissions of this cycle (slot of the first, count) and
  * *n_logits how many predictions were written to `logits` ([CSK_CO_MAX_CYCLE][N][classes], slice j = prediction j). */

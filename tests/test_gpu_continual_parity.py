@@ -232,3 +232,56 @@ def test_blocks_accept_a_foreign_graph_conv_module(ci, co, stride):
     co_blk.load_state_dict(sd, strict=True)
     steps = co_blk.to(DEV).forward_steps(x.to(DEV), pad_end=True).cpu()
     assert steps.shape == want.shape and max_err(steps, want) <= TOL
+
+
+def test_update_state_false_peeks_without_advancing():
+    """forward_step / forward_steps(update_state=False) (models/base.py:183-190 pass the flag through): the output
+    equals what the real step produces, and a stream that was peeked at continues exactly -- bit for bit -- like a
+    twin that never was.  Block level, model level on the native executor and on the Python engine."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:2, :, :120].to(DEV)
+    for native_plan in (True, False):
+        twins = []
+        for _ in range(2):
+            co = pkg.CoStGcn(A, pool_size=4, pool_padding=1).eval()
+            co.use_native_plan = native_plan
+            co.load_state_dict(sd, strict=True)
+            twins.append(co.to(DEV))
+        peeker, plain = twins
+        for t in range(120):
+            f = x[:, :, t].contiguous()
+            if t in (0, 3, 50, 83, 84, 100):
+                p1 = peeker.forward_step(f, update_state=False)
+                p2 = peeker.forward_step(f, update_state=False)            # peeking twice changes nothing either
+                assert (p1 is None) == (p2 is None) and (p1 is None or torch.equal(p1, p2))
+            if t == 90:                                                      # a multi-frame peek (copies the slab)
+                ahead = peeker.forward_steps(x[:, :, 90:110].contiguous(), update_state=False)
+                assert ahead.shape[2] == 5                                   # predictions at frames 92, 96, ..., 108
+            got, want = peeker.forward_step(f), plain.forward_step(f)
+            assert (got is None) == (want is None)
+            if want is not None:
+                assert torch.equal(got, want), (native_plan, t)
+                if t in (83, 84, 100) and p1 is not None:
+                    assert torch.equal(p1, want)
+            if t == 108:
+                assert torch.equal(ahead[:, :, -1], want)                   # the look-ahead saw the same prediction
+    # block level (identity residual, stride 1) and the bare continual temporal conv
+    blk = pkg.CoSpatioTemporalBlock(6, 6, A, padding=4).eval().to(DEV)
+    twin = pkg.CoSpatioTemporalBlock(6, 6, A, padding=4).eval()
+    twin.load_state_dict(blk.state_dict(), strict=True)
+    twin = twin.to(DEV)
+    tc = pkg.CoTemporalConvolution(6, 6, padding="equal").eval().to(DEV)
+    tc_twin = pkg.CoTemporalConvolution(6, 6, padding="equal").eval()
+    tc_twin.load_state_dict(tc.state_dict(), strict=True)
+    tc_twin = tc_twin.to(DEV)
+    xb = torch.rand(3, 6, 30, 25, device=DEV)
+    for m, tw in ((blk, twin), (tc, tc_twin)):
+        for t in range(30):
+            f = xb[:, :, t].contiguous()
+            peek = m.forward_step(f, update_state=False)
+            if t == 12:
+                m.forward_steps(xb[:, :, 12:26].contiguous(), update_state=False)
+            got, want = m.forward_step(f), tw.forward_step(f)
+            assert (got is None) == (want is None) == (peek is None)
+            if want is not None:
+                assert torch.equal(got, want) and torch.equal(peek, want), t
