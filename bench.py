@@ -339,7 +339,7 @@ def main():
             line = {"metric": step_info["metric"], "value": step_info["value"], "unit": "frames/s", "n_gpus": world,
                     "steps": args.step_cycles, "warmup": 2, "ms_per_step": round(sdt / args.step_cycles * 1e3, 3),
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                    "config": {"workload": f"CoST-GCN online step, {args.streams} streams/GPU, NTU-60, one step = 4 frames [configs[2]]",
+                    "config": {"workload": f"CoST-GCN online step, {args.streams} streams/GPU, NTU-60, one step = {args.frames_per_launch} frames [configs[2]]",
                                "parallelism": f"stream-shard x{world}"},
                     "roofline": step_info["roofline"], "cpu_baseline": cpu_step}
         else:
