@@ -22,6 +22,7 @@ struct GcnParams {
     int adj_per_frame;   // the (dense) adjacency varies per FRAME of a segment: index = seg * frames + frame
     int lds_frames;      // frames of adjacency staged per workgroup in that mode
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup of the sparse kernel
+    int fast_epi;        // channel strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
 };
 
 template <int MT, int NJ>
@@ -148,30 +149,80 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
         mfma_chunk<MT>(Wl, Xa, R, NT, KC * NT, offA, off0, off1, kh, acc);
     }
 
+    // epilogue: ReLU(acc + bias + identity residual), same scheme as the sparse kernel below (scalar row bases +
+    // 32-bit lane offsets on full tiles, permlane32_swap for 256-B row segments)
     float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
     const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    const int rbase = m0 + wm * 64;
+    const bool full = p.fast_epi && m0 + MT <= p.Cout;
+    const unsigned kh4 = 4u * (unsigned)kh;
+    float bb[2][16], rv[2][2][16];
+    if (full) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = q0 + wn * 64 + ni * 32 + l31;
-        const bool qv = q < Q;
-        const int qc = min(q, Q - 1);
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
-            float bv[16], rv[16];
+            for (int g = 0; g < 16; ++g) bb[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                bv[g] = p.bias[co];
-                rv[g] = ident ? seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc] : 0.f;
-            }
+        for (int ni = 0; ni < 2; ++ni) {
+            const unsigned lo = 4u * (kh4 * (unsigned)p.x_chan_stride + (unsigned)min(q0 + wn * 64 + ni * 32 + l31, Q - 1));
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                const float v = fmaxf(acc[mi][ni][g] + bv[g] + rv[g], 0.f);
-                if (qv && co < p.Cout) oseg[(int64_t)co * p.y_chan_stride + q] = v;
-            }
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float *rrow = seg_base + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.x_chan_stride;
+                    rv[ni][mi][g] = ident ? ld_lane(rrow, lo) : 0.f;
+                }
         }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bb[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    rv[ni][mi][g] = ident ? seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc] : 0.f;
+                }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float v0 = fmaxf(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g], 0.f);
+            const float v1 = fmaxf(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g], 0.f);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+            acc[mi][0][g] = __uint_as_float(sw[0]);
+            acc[mi][1][g] = __uint_as_float(sw[1]);
+        }
+    const int qb = q0 + wn * 64 + lane;
+    const bool qv = qb < Q;
+    if (full) {
+        if (qv) {
+            const unsigned qo = 4u * (unsigned)qb;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.y_chan_stride;
+                    st_lane(orow, qo, acc[mi][0][g]);
+                    st_lane(orow + 4 * p.y_chan_stride, qo, acc[mi][1][g]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
+                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = acc[mi][0][g];
+                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = acc[mi][1][g];
+            }
     }
 }
 
@@ -338,21 +389,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
     commit();                                              // so the epilogue operands are loaded under its MFMAs
     __syncthreads();
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
+    // Epilogue operands.  Rows of this wave: rbase + mi*32 + (g & 3) + 8*(g >> 2) (+ 4*kh in the accumulator
+    // layout).  Everything but the lane's own offset is wave-uniform, so on full tiles (all MT rows exist) the
+    // row base pointers are formed on the scalar unit and each load / store carries one 32-bit lane offset; the
+    // general form (clamped rows, per-element predicates) costs ~13 instructions per access and is kept for
+    // ragged channel counts only.
+    const int rbase = m0 + wm * 64;
+    const bool full = p.fast_epi && m0 + MT <= p.Cout;
+    const unsigned kh4 = 4u * (unsigned)kh;
     float bb[2][16], rv[2][2][16];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) bb[mi][g] = p.bias[m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+    if (full) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int co = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
-                rv[ni][mi][g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
-            }
+            for (int g = 0; g < 16; ++g) bb[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const unsigned lo = 4u * (kh4 * (unsigned)p.x_chan_stride + (unsigned)min(q0 + wn * 64 + ni * 32 + l31, Q - 1));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float *rrow = seg_base + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.x_chan_stride;
+                    rv[ni][mi][g] = CONVRES ? 0.f : ld_lane(rrow, lo);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bb[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    rv[ni][mi][g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
+                }
+        }
     }
     mfma_steps(0, KCG / 2);
     unsigned long long st3 = 0;
@@ -367,13 +444,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const int row0 = m0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2);
             const float v0 = fmaxf(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g], 0.f);
             const float v1 = fmaxf(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g], 0.f);
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
-            if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = __uint_as_float(sw[0]);
-            if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = __uint_as_float(sw[1]);
+            acc[mi][0][g] = __uint_as_float(sw[0]);       // row (g & 3) + 8*(g >> 2), column qb
+            acc[mi][1][g] = __uint_as_float(sw[1]);       // row + 4
         }
+    if (full) {
+        if (qv) {
+            const unsigned qo = 4u * (unsigned)qb;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.y_chan_stride;
+                    st_lane(orow, qo, acc[mi][0][g]);
+                    st_lane(orow + 4 * p.y_chan_stride, qo, acc[mi][1][g]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
+                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = acc[mi][0][g];
+                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = acc[mi][1][g];
+            }
+    }
     if (p.stamps && lane == 0) {   // [wg][wave][8]: start, loop start, last-chunk start, mfma end, end, wait/commit/mfma sums
         unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memtime(); o[5] = ph0; o[6] = ph1; o[7] = ph2;
@@ -419,6 +517,7 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     p.dense = adj_seg_stride != 0 && ell_w == V && ell_cnt[0] == V && ell_cnt[1] == V && ell_cnt[2] == V;
     p.adj_per_frame = adj_per_frame != 0;
     p.stamps = csk_diag_stamps();
+    p.fast_epi = x_chan_stride < (1ll << 28) && y_chan_stride < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
     if (p.adj_per_frame && !p.dense) CSK_FAIL("gcn_stage: per-frame adjacency must be dense (ell_w == V, ell_cnt == V)");
     p.vmagic = vmagic_of(V);
     const bool big = (p.Mpad % 128) == 0;

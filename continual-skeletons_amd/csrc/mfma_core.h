@@ -42,6 +42,15 @@ __device__ __forceinline__ int div_magic(int x, unsigned magic) {
 // linear blockIdx puts neighbouring tiles -- which share temporal halos and weight panels -- on eight
 // different L2s.  Remap so that every XCD walks a CONTIGUOUS range of work items (bijective for any grid
 // size; placement is a speed assumption only, never a correctness one).
+// Access through a wave-uniform row pointer plus a 32-bit per-lane BYTE offset: lets the compiler keep the row base in
+// SGPRs (global_load/store "saddr" form) instead of materialising a 64-bit address per lane and access.
+__device__ __forceinline__ float ld_lane(const float *row, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(row) + byte_off);
+}
+__device__ __forceinline__ void st_lane(float *row, unsigned byte_off, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(row) + byte_off) = v;
+}
+
 __device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned total) {
     const unsigned q = total / 8, r = total % 8, xcd = bid % 8, k = bid / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;

@@ -63,6 +63,7 @@ struct StepParams {
     int C, Cpad, Cout, Mpad, K, slots, head, head_step;
     int res_mode, Cres, CresPad, relu;
     int xres_slots, xres_slot0, xres_step, out_slots, out_slot0;
+    int fast_epi;      // P fits the 32-bit lane byte offsets of the scalar-base epilogue addressing
     int64_t P;
 };
 
@@ -165,31 +166,81 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
             mfma_chunk<MT>(Wl, Bl, 1, NT, KC * NT, offA, off0, off1, kh, acc);
         }
     }
-    // ---- epilogue
+    // ---- epilogue: + bias (+ identity residual), ReLU, stores.  Same scheme as tcn_stage_kernel: on full tiles the row
+    // base pointers are wave-uniform (scalar unit) and every access carries one 32-bit lane byte offset;
+    // v_permlane32_swap pairs the ni = 0 / 1 registers so that a store instruction writes one 256-B row segment.
     const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    const int rbase = m0 + wm * 64;
+    const bool full = p.fast_epi && m0 + MT <= p.Cout;
+    const unsigned kh4 = 4u * (unsigned)kh;
+    float bv[2][16], rv[2][2][16];
+    if (full) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = p0 + wn * 64 + ni * 32 + l31;
-        const bool qv = q < P;
-        const int64_t qc = min((int64_t)q, P - 1);
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int cb = m0 + wm * 64 + mi * 32 + 4 * kh;
-            float bv[16], rv[16];
+            for (int g = 0; g < 16; ++g) bv[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                bv[g] = p.bias[co];
-                rv[g] = ident ? xres[(int64_t)min(co, p.Cout - 1) * P + qc] : 0.f;
-            }
+        for (int ni = 0; ni < 2; ++ni) {
+            const unsigned lo = 4u * (kh4 * (unsigned)P + (unsigned)min((int64_t)(p0 + wn * 64 + ni * 32 + l31), P - 1));
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int co = cb + (g & 3) + 8 * (g >> 2);
-                float v = acc[mi][ni][g] + bv[g] + rv[g];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (qv && co < p.Cout) out[(int64_t)co * P + q] = v;
-            }
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float *rrow = xres + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * P;
+                    rv[ni][mi][g] = ident ? ld_lane(rrow, lo) : 0.f;
+                }
         }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int64_t qc = min((int64_t)(p0 + wn * 64 + ni * 32 + l31), P - 1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    rv[ni][mi][g] = ident ? xres[(int64_t)min(co, p.Cout - 1) * P + qc] : 0.f;
+                }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
+            float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
+            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+            acc[mi][0][g] = __uint_as_float(sw[0]);            // row rbase + mi*32 + (g&3) + 8(g>>2), column qb
+            acc[mi][1][g] = __uint_as_float(sw[1]);            // row + 4
+        }
+    const int64_t qb = (int64_t)p0 + wn * 64 + lane;
+    const bool qv = qb < P;
+    if (full) {
+        if (qv) {
+            const unsigned qo = 4u * (unsigned)qb;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float *orow = out + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * P;
+                    st_lane(orow, qo, acc[mi][0][g]);
+                    st_lane(orow + 4 * P, qo, acc[mi][1][g]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
+                if (qv && row0 < p.Cout) out[(int64_t)row0 * P + qb] = acc[mi][0][g];
+                if (qv && row0 + 4 < p.Cout) out[(int64_t)(row0 + 4) * P + qb] = acc[mi][1][g];
+            }
     }
 }
 
@@ -249,6 +300,7 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.K = k; p.slots = slots; p.head = head; p.head_step = head_step; p.res_mode = res_mode;
     p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD); p.relu = relu; p.P = P;
+    p.fast_epi = P < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
     p.xres_slots = x_res ? x_res_slots : 1; p.xres_slot0 = x_res ? x_res_slot0 : 0; p.xres_step = x_res_step;
     p.out_slots = out_slots; p.out_slot0 = out_slot0;
     const bool big = (p.Mpad % 128) == 0;

@@ -27,6 +27,7 @@ struct TcnParams {
     int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
     unsigned vmagic, mtiles, qtiles;
     int nt;                       // positions per tile actually used (<= 16384 / MT)
+    int fast_epi;                 // row strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
     int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
@@ -79,11 +80,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     const int64_t rcs = (int64_t)p.Tres * V;
     const bool ident = p.res_mode == CSK_RES_IDENTITY;
     float bv[2][16], rv[2][2][16];
+    // Rows of this wave: rbase + mi*32 + (g & 3) + 8*(g >> 2) (+ 4*kh in the accumulator layout); everything but the
+    // lane's own offset is wave-uniform.  On full tiles (all MT rows exist) the row base pointers are formed on the
+    // scalar unit and each access carries one 32-bit lane byte offset (ld_lane / st_lane); the general form
+    // (clamped rows, per-element predicates, ~13 instructions per access) is kept for ragged channel counts.
+    const int rbase = m0 + wm * 64;
+    const bool full = p.fast_epi && m0 + MT <= p.Cout;
+    const unsigned kh4 = 4u * (unsigned)kh;
     auto issue_epilogue_loads = [&]() {
+        if (full) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) bv[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
+                const int t = div_magic(qc, p.vmagic);
+                const unsigned qres = ident ? 4u * (kh4 * (unsigned)rcs + (unsigned)((t * p.stride + p.res_off) * V + (qc - t * V))) : 0u;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const float *rrow = rseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * rcs;
+                        rv[ni][mi][g] = ident ? ld_lane(rrow, qres) : 0.f;
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+            for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
@@ -93,7 +121,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const int co = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
                     rv[ni][mi][g] = ident ? rseg[(int64_t)min(co, p.Cout - 1) * rcs + qres] : 0.f;
                 }
         }
@@ -195,16 +223,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int co_own = m0 + wm * 64 + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
                 float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
                 float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
-                // sw[0]: row (co_own - 4*kh), this lane's column qb; sw[1]: row (co_own - 4*kh + 4)
-                const int row0 = co_own - 4 * kh;
-                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * Q + qb] = __uint_as_float(sw[0]);
-                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * Q + qb] = __uint_as_float(sw[1]);
+                acc[mi][0][g] = __uint_as_float(sw[0]);        // row rbase + mi*32 + (g&3) + 8(g>>2), this lane's column qb
+                acc[mi][1][g] = __uint_as_float(sw[1]);        // row + 4
             }
+        if (full) {
+            if (qv) {
+                const unsigned qo = 4u * (unsigned)qb;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * Q;
+                        st_lane(orow, qo, acc[mi][0][g]);
+                        st_lane(orow + 4 * (int64_t)Q, qo, acc[mi][1][g]);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
+                    if (qv && row0 < p.Cout) oseg[(int64_t)row0 * Q + qb] = acc[mi][0][g];
+                    if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * Q + qb] = acc[mi][1][g];
+                }
+        }
     }
     if (p.stamps && tid == 0) {
         unsigned long long st3 = __builtin_amdgcn_s_memtime();
@@ -252,6 +299,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
     p.stamps = csk_diag_stamps();
     p.prio = !csk_diag_flag("CSK_NOPRIO");
+    p.fast_epi = (int64_t)p.Tres * V < (1ll << 28) && (int64_t)t_out * V < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     // the register staging holds <= 14 x 64 positions of an activation row; tiles whose input span (stride * frames

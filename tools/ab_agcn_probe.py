@@ -1,0 +1,18 @@
+import os, sys, time, statistics
+os.environ["CSK_DIAG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, _bootstrap, bench
+pkg = _bootstrap.load()
+dev = "cuda:0"; A = pkg.kinetics_graph().A; shape = (3, 300, 18, 2)
+x = torch.rand((64,) + shape, device=dev)
+net = pkg.AGcn(A, shape, 400).eval(); bench.randomise_(net, 0); net = net.to(dev)
+res = {0: [], 1: []}
+for rnd in range(8):
+    for flag in (0, 1):
+        if flag: os.environ["CSK_SLOW_EPI"] = "1"
+        else: os.environ.pop("CSK_SLOW_EPI", None)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): net(x)
+        torch.cuda.synchronize()
+        if rnd >= 2: res[flag].append((time.perf_counter() - t0) / 3 * 1e3)
+print(f"AGCN clip b64: fast {statistics.median(res[0]):.3f} ms | slow-epilogue {statistics.median(res[1]):.3f} ms")

@@ -9,8 +9,8 @@ import _bootstrap
 pkg = _bootstrap.load()
 dev = "cuda:0"
 A = pkg.ntu_graph().A
-for (ci, co, t) in [(64, 64, 300), (64, 128, 300), (128, 128, 150), (256, 256, 75)]:
-    nm = 512
+NMS = [int(a) for a in sys.argv[1:]] or [512]
+for (ci, co, t, nm) in [(c[0], c[1], c[2], nm) for nm in NMS for c in [(64, 64, 300), (64, 128, 300), (128, 128, 150), (256, 256, 75)]]:
     blk = pkg.SpatioTemporalBlock(ci, co, A, stride=1, residual=True).eval().to(dev)
     x = torch.rand(nm, ci, t, 25, device=dev)
     NT = 128 if co % 128 == 0 else 256
@@ -33,7 +33,7 @@ for (ci, co, t) in [(64, 64, 300), (64, 128, 300), (128, 128, 150), (256, 256, 7
     pro, loop, last, epi = st[..., 1] - st[..., 0], st[..., 2] - st[..., 1], st[..., 3] - st[..., 2], st[..., 4] - st[..., 3]
     tot = st[..., 4] - st[..., 0]
     med = lambda a: float(np.median(a))  # noqa: E731
-    print(f"C {ci}->{co}: {nwg} WGs, {ms_plain:.3f} ms plain / {ms_st:.3f} ms stamped; ticks of 10 ns per wave (median):")
+    print(f"C {ci}->{co} nm={nm}: {nwg} WGs, {ms_plain:.3f} ms plain / {ms_st:.3f} ms stamped; ticks of 10 ns per wave (median):")
     print(f"   prologue {med(pro):.0f} | loop {med(loop):.0f} ({chunks} chunks: wait-barrier1 {med(st[..., 5]) / chunks:.0f} commit+barrier2 {med(st[..., 6]) / chunks:.0f}"
           f" issue+mfma {med(st[..., 7]) / chunks:.0f} per chunk) | last chunk incl. commit {med(last):.0f} | epilogue {med(epi):.0f} | total {med(tot):.0f}")
     span = st[..., 4].max() - st[..., 0].min()
