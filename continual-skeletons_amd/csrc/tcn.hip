@@ -265,16 +265,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-// pick the <MT, NJ> instantiation, raise its dynamic-LDS cap, launch
-template <typename P, typename K>
-static int launch_stage(bool big, bool small_span, dim3 grid, size_t lds, hipStream_t s, const P &p, K k128a, K k128b,
-                        K k64a, K k64b) {
-    K k = big ? (small_span ? k128a : k128b) : (small_span ? k64a : k64b);
-    if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
-    hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds, s, p);
-    return (int)hipGetLastError();
-}
-
 extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
                                  const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,
                                  int stride, int pad, int res_mode, int c_res, int t_res, int res_off, int relu,
@@ -312,15 +302,22 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
         if ((p.ldb + 63) / 64 <= 14 || p.nt == 1) break;
         p.nt = p.nt > 16 ? p.nt - 16 : 1;
     }
+    const int nj = (p.ldb + 63) / 64;
+    if (nj > 14) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
     const size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
     if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = t_out * V;
     p.qtiles = (Q + p.nt - 1) / p.nt; p.mtiles = p.Mpad / MT;
     if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage: grid too large");
     dim3 grid(p.qtiles * p.mtiles * n_seg);
-    const int nj = (p.ldb + 63) / 64;
-    if (nj > 14) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
-    return launch_stage(big, nj <= 9, grid, lds, (hipStream_t)stream, p,
-                        tcn_stage_kernel<128, 9>, tcn_stage_kernel<128, 14>, tcn_stage_kernel<64, 9>, tcn_stage_kernel<64, 14>);
+    // NJ = 64-lane sweeps of the activation staging per row: the smallest instantiation that covers the span (sweeps
+    // beyond it re-load and re-commit its last position: wasted load / LDS-write slots).  128x128 tiles of the
+    // stride-1 layers need 6 sweeps, not 9: -2.7 % on their tiles.
+    void (*kern)(TcnParams) =
+        big ? (nj <= 6 ? tcn_stage_kernel<128, 6> : nj <= 9 ? tcn_stage_kernel<128, 9> : tcn_stage_kernel<128, 14>)
+            : (nj <= 6 ? tcn_stage_kernel<64, 6> : nj <= 9 ? tcn_stage_kernel<64, 9> : tcn_stage_kernel<64, 14>);
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
 }
 

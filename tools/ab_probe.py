@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Interleaved in-process A/B of a diagnostic env switch on the TCN stage (guide rule 24).
-usage: CSK_DIAG=1 python tools/ab_probe.py CSK_NOPRIO"""
+usage: python tools/ab_probe.py CSK_NOPRIO   |   python tools/ab_probe.py CSK_LDB_PAD=-1"""
 import os, sys
 os.environ["CSK_DIAG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, statistics
 import _bootstrap
 pkg = _bootstrap.load()
-var = sys.argv[1]
+var, _, val = sys.argv[1].partition("=")
+val = val or "1"
 dev = "cuda:0"; A = pkg.ntu_graph().A
 for (ci, co, s, t) in [(64, 64, 1, 300), (128, 128, 1, 150), (256, 256, 1, 75)]:
     blk = pkg.SpatioTemporalBlock(ci, co, A, stride=s).eval().to(dev)
@@ -15,7 +16,7 @@ for (ci, co, s, t) in [(64, 64, 1, 300), (128, 128, 1, 150), (256, 256, 1, 75)]:
     res = {0: [], 1: []}
     for rnd in range(12):
         for flag in (0, 1):
-            if flag: os.environ[var] = "1"
+            if flag: os.environ[var] = val
             else: os.environ.pop(var, None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -24,4 +25,4 @@ for (ci, co, s, t) in [(64, 64, 1, 300), (128, 128, 1, 150), (256, 256, 1, 75)]:
             if rnd >= 2: res[flag].append(e0.elapsed_time(e1))
     os.environ.pop(var, None)
     m0, m1 = statistics.median(res[0]), statistics.median(res[1])
-    print(f"C={co}: default {m0:.3f} ms (min {min(res[0]):.3f}) | {var}=1 {m1:.3f} ms (min {min(res[1]):.3f}) | ratio {m1/m0:.4f}")
+    print(f"C={co}: default {m0:.3f} ms (min {min(res[0]):.3f}) | {var}={val} {m1:.3f} ms (min {min(res[1]):.3f}) | ratio {m1/m0:.4f}")

@@ -9,8 +9,8 @@ pkg = _bootstrap.load()
 from continual_skeletons_amd.models import layer_table
 dev = "cuda:0"
 A = pkg.ntu_graph().A
-for (ci, co, s, res, t) in [(64, 64, 1, True, 300), (256, 256, 1, True, 75)]:
-    nm = 512
+for (ci, co, s, res, t) in [(64, 64, 1, True, 300), (128, 128, 1, True, 150), (256, 256, 1, True, 75)]:
+    nm = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     blk = pkg.SpatioTemporalBlock(ci, co, A, stride=s, residual=res).eval().to(dev)
     x = torch.rand(nm, ci, t, 25, device=dev)
     y = blk.gcn(x)
@@ -33,7 +33,7 @@ for (ci, co, s, res, t) in [(64, 64, 1, True, 300), (256, 256, 1, True, 75)]:
     tot = st[:, 3] - st[:, 0]
     print(f"C={co}: WGs {nwg}; cycles (s_memtime ticks = 100MHz? check): prologue med {np.median(pro):.0f} p90 {np.percentile(pro,90):.0f} | loop med {np.median(loop):.0f} | epilogue med {np.median(epi):.0f} p90 {np.percentile(epi,90):.0f} | total med {np.median(tot):.0f}")
     span = st[:, 3].max() - st[:, 0].min()
-    print(f"   kernel span {span} ticks; sum(total)/span = {tot.sum()/span:.1f} concurrent WGs; start spread first 512: {np.sort(st[:,0])[511]-st[:,0].min()}")
+    print(f"   kernel span {span} ticks; sum(total)/span = {tot.sum()/span:.1f} concurrent WGs; start spread first 512: {np.sort(st[:,0])[min(511, len(st) - 1)]-st[:,0].min()}")
     # gap between a WG end and the next WG start on the same CU slot
     hw = st[:, 4] & 0xFFFFFFFF
     cu_key = (st[:, 5] << 32) | (hw & 0xFFFF00)   # xcc + se/sh/cu bits (approx)
