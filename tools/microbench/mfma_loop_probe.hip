@@ -151,12 +151,87 @@ __global__ __launch_bounds__(256, OCC) void struct_kernel(float *out, const floa
     out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int L, int OCC = 2> double run_struct(int chunks, int blocks) {
+
+// PIPE variant: the same traffic per 8 channels as struct 3, but as two 4-channel half-chunks with ping-pong LDS
+// buffers (same LDS footprint): the commit of half h+1 and the loads of half h+2 have no dependency on the MFMAs of
+// half h, and there is one barrier per half-chunk.  halves = 2 * chunks.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void pipe_kernel(float *out, const float *gw, const float *gb, int halves) {
+    constexpr int HC = KC / 2;                          // channels per half-chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WSZ = TAPS * HC * MT, BSZ = HC * LDB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < 2 * (WSZ + BSZ); i += 256) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
+    __syncthreads();
+    const int offA = (wave & 1) * 64 + l31, off0 = (wave >> 1) * 64 + l31, off1 = off0 + 32;
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    // half-chunk staging: W 9*4*128 floats = 4.5 f32x4 per thread -> 5 (last half-used), B 4 rows * 376 -> 9 dwords (6 sweeps of 64 over 2 rows... modelled as 9)
+    f32x4 wv[5];
+    float bv[9];
+    for (int u = 0; u < 5; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(gw + (u * 256 + tid) * 4);
+    for (int u = 0; u < 9; ++u) bv[u] = gb[(size_t)blockIdx.x * 65536 + u * 256 + tid];
+    for (int h = 0; h < halves; ++h) {
+        float *Wc = smem + (h & 1) * (WSZ + BSZ), *Bc = Wc + WSZ;                 // buffers read by this half's MFMAs
+        float *Wn = smem + ((h + 1) & 1) * (WSZ + BSZ), *Bn = Wn + WSZ;           // buffers the next half is committed to
+        const float *gwc = gw + (size_t)((h + 2) & 31) * 4608, *gbc = gb + (size_t)blockIdx.x * 65536 + (size_t)((h + 2) & 7) * 2304;
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3) {
+            if (g3 == 1) {                                 // after the first tap segment: commit next half, reload staging regs
+#pragma unroll
+                for (int u = 0; u < 5; ++u) if (u < 4 || tid < 128) *reinterpret_cast<f32x4 *>(Wn + (u * 256 + tid) * 4) = wv[u];
+#pragma unroll
+                for (int u = 0; u < 9; ++u) Bn[(u % HC) * LDB + (u / HC) * 128 + (tid & 127)] = bv[u] + (float)(tid >> 7);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(gwc + (u * 256 + tid) * 4);
+#pragma unroll
+                for (int u = 0; u < 9; ++u) bv[u] = gbc[u * 256 + tid];
+            }
+            for (int r = 3 * g3; r < 3 * g3 + 3; ++r) {
+                const float *wr = Wc + r * (HC * MT) + offA + kh * MT, *br = Bc + r * 25 + kh * LDB;
+#pragma unroll
+                for (int s2 = 0; s2 < HC / 2; ++s2) {
+                    const float a0 = wr[2*s2*MT], a1 = wr[2*s2*MT+32], b0 = br[2*s2*LDB+off0], b1 = br[2*s2*LDB+off1];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) s += acc[a][b][g];
+    for (int u = 0; u < 5; ++u) s += wv[u][0];
+    for (int u = 0; u < 9; ++u) s += bv[u];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int OCC> double run_pipe(int chunks, int blocks, size_t lds_extra = 0) {
     float *out, *gw, *gb;
     hipMalloc(&out, (size_t)blocks * 256 * 4);
     hipMalloc(&gw, (size_t)32 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)32 * 9216 * 4 + 65536);
     hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
-    const size_t lds = (TAPS * KC * MT + KC * LDB) * 4;
+    const size_t lds = (size_t)2 * (TAPS * (KC / 2) * MT + (KC / 2) * LDB) * 4 + lds_extra;
+    hipFuncSetAttribute((const void *)pipe_kernel<OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((pipe_kernel<OCC>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, 2 * chunks);
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((pipe_kernel<OCC>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, 2 * chunks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    hipFree(out); hipFree(gw); hipFree(gb);
+    const double flops = (double)blocks * 4 * chunks * TAPS * (KC / 2) * 4 * 4096.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
+template <int L, int OCC = 2> double run_struct(int chunks, int blocks, size_t lds_extra = 0) {
+    float *out, *gw, *gb;
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipMalloc(&gw, (size_t)32 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)32 * 9216 * 4 + 65536);
+    hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
+    const size_t lds = (TAPS * KC * MT + KC * LDB) * 4 + lds_extra;
     hipFuncSetAttribute((const void *)struct_kernel<L, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((struct_kernel<L, OCC>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
@@ -169,9 +244,9 @@ template <int L, int OCC = 2> double run_struct(int chunks, int blocks) {
     return flops / (ms * 1e-3) / 1e12;
 }
 
-template <int V> double run(int chunks, int blocks) {
+template <int V> double run(int chunks, int blocks, size_t lds_extra = 0) {
     float *out; hipMalloc(&out, (size_t)blocks * 256 * 4);
-    const size_t lds = (TAPS * KC * MT + KC * LDB) * 4;
+    const size_t lds = (TAPS * KC * MT + KC * LDB) * 4 + lds_extra;   // lds_extra > 32 KB forces one workgroup per CU
     hipFuncSetAttribute((const void *)loop_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(loop_kernel<V>, dim3(blocks), dim3(256), lds, 0, out, chunks);
@@ -193,6 +268,13 @@ int main() {
     printf("struct 1 (+ 2 barriers per chunk):                      %.1f TFLOP/s\n", run_struct<1>(chunks, blocks));
     printf("struct 2 (+ LDS commit of 9 f32x4 + 18 dwords):         %.1f TFLOP/s\n", run_struct<2>(chunks, blocks));
     printf("struct 3 (+ 27 global prefetch loads in 3 bursts):      %.1f TFLOP/s\n", run_struct<3>(chunks, blocks));
+    printf("struct 3 at 1 workgroup/CU:                             %.1f TFLOP/s\n", run_struct<3>(chunks, 256 * 6, 48 * 1024));
+    printf("pipe (4-channel halves, ping-pong LDS, 1 barrier) 2 WG/CU: %.1f TFLOP/s\n", run_pipe<2>(chunks, blocks));
+    printf("pipe at 1 workgroup/CU:                                   %.1f TFLOP/s\n", run_pipe<2>(chunks, 256 * 6, 64 * 1024));
+    // one workgroup per CU (one wave per SIMD): what a lone wave gets out of the pipe
+    printf("variant 0 at 1 workgroup/CU (LDS, pipelined reads):     %.1f TFLOP/s\n", run<0>(chunks, 256 * 6, 48 * 1024));
+    printf("variant 1 at 1 workgroup/CU (LDS, compiler-scheduled):  %.1f TFLOP/s\n", run<1>(chunks, 256 * 6, 48 * 1024));
+    printf("variant 2 at 1 workgroup/CU (register operands):        %.1f TFLOP/s\n", run<2>(chunks, 256 * 6, 48 * 1024));
     // the same structure with three workgroups per CU (3 waves/SIMD, <= 168 VGPRs, 3 x 48.9 KB LDS)
     printf("struct 0 at 3 workgroups/CU:                            %.1f TFLOP/s\n", run_struct<0, 3>(chunks, 768 * 4));
     printf("struct 3 at 3 workgroups/CU:                            %.1f TFLOP/s\n", run_struct<3, 3>(chunks, 768 * 4));
