@@ -226,6 +226,82 @@ template <int OCC> double run_pipe(int chunks, int blocks, size_t lds_extra = 0)
     return flops / (ms * 1e-3) / 1e12;
 }
 
+
+// The same cumulative structure for the 64x256 tile of the narrow layers (all four waves share the 64 weight rows):
+// 4.5 f32x4 of W and 18 dwords of B per thread and chunk, B rows of 500 positions.
+template <int LEVEL>
+__global__ __launch_bounds__(256, 2) void struct64_kernel(float *out, const float *gw, const float *gb, int chunks) {
+    constexpr int M6 = 64, L6 = 500, NW = 5, NB = 18;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem, *Bl = smem + TAPS * KC * M6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < TAPS * KC * M6 + KC * L6; i += 256) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
+    __syncthreads();
+    const int offA = l31, off0 = wave * 64 + l31, off1 = off0 + 32;
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    f32x4 wv[NW];
+    float bv[NB];
+    const int wlim = TAPS * KC * M6 / 4;
+    for (int u = 0; u < NW; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(gw + (u * 256 + tid) * 4);
+    for (int u = 0; u < NB; ++u) bv[u] = gb[(size_t)blockIdx.x * 65536 + u * 256 + tid];
+    for (int c = 0; c < chunks; ++c) {
+        if (LEVEL >= 1) __syncthreads();
+        if (LEVEL >= 2) {
+#pragma unroll
+            for (int u = 0; u < NW; ++u)
+                if (u * 256 + tid < wlim) *reinterpret_cast<f32x4 *>(Wl + (u * 256 + tid) * 4) = wv[u];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) Bl[(u % KC) * L6 + (u / KC) * 128 + (tid & 127)] = bv[u] + (float)(tid >> 7);
+        }
+        if (LEVEL >= 1) __syncthreads();
+        const float *gwc = gw + (size_t)((c + 1) & 31) * 9216, *gbc = gb + (size_t)blockIdx.x * 65536 + (size_t)((c + 1) & 7) * 4608;
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3) {
+            if (LEVEL >= 3) {
+#pragma unroll
+                for (int u = g3; u < NW; u += 3) wv[u] = *reinterpret_cast<const f32x4 *>(gwc + (u * 256 + tid) * 4);
+#pragma unroll
+                for (int u = g3; u < NB; u += 3) bv[u] = gbc[u * 256 + tid];
+            }
+            for (int r = 3 * g3; r < 3 * g3 + 3; ++r) {
+                const float *wr = Wl + r * (KC * M6) + offA + kh * M6, *br = Bl + r * 25 + kh * L6;
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    const float a0 = wr[2*s*M6], a1 = wr[2*s*M6+32], b0 = br[2*s*L6+off0], b1 = br[2*s*L6+off1];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) s += acc[a][b][g];
+    for (int u = 0; u < NW; ++u) s += wv[u][0];
+    for (int u = 0; u < NB; ++u) s += bv[u];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int L> double run_struct64(int chunks, int blocks) {
+    float *out, *gw, *gb;
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipMalloc(&gw, (size_t)32 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)32 * 9216 * 4 + 65536);
+    hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
+    const size_t lds = (size_t)(TAPS * KC * 64 + KC * 500) * 4;
+    hipFuncSetAttribute((const void *)struct64_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((struct64_kernel<L>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((struct64_kernel<L>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    hipFree(out); hipFree(gw); hipFree(gb);
+    const double flops = (double)blocks * 4 * chunks * TAPS * (KC / 2) * 4 * 4096.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
 template <int L, int OCC = 2> double run_struct(int chunks, int blocks, size_t lds_extra = 0) {
     float *out, *gw, *gb;
     hipMalloc(&out, (size_t)blocks * 256 * 4);
@@ -268,6 +344,8 @@ int main() {
     printf("struct 1 (+ 2 barriers per chunk):                      %.1f TFLOP/s\n", run_struct<1>(chunks, blocks));
     printf("struct 2 (+ LDS commit of 9 f32x4 + 18 dwords):         %.1f TFLOP/s\n", run_struct<2>(chunks, blocks));
     printf("struct 3 (+ 27 global prefetch loads in 3 bursts):      %.1f TFLOP/s\n", run_struct<3>(chunks, blocks));
+    printf("64x256 tile: struct 0 / 1 / 2 / 3 at 2 workgroups/CU:     %.1f / %.1f / %.1f / %.1f TFLOP/s\n", run_struct64<0>(chunks, blocks),
+           run_struct64<1>(chunks, blocks), run_struct64<2>(chunks, blocks), run_struct64<3>(chunks, blocks));
     printf("struct 3 at 1 workgroup/CU:                             %.1f TFLOP/s\n", run_struct<3>(chunks, 256 * 6, 48 * 1024));
     printf("pipe (4-channel halves, ping-pong LDS, 1 barrier) 2 WG/CU: %.1f TFLOP/s\n", run_pipe<2>(chunks, blocks));
     printf("pipe at 1 workgroup/CU:                                   %.1f TFLOP/s\n", run_pipe<2>(chunks, 256 * 6, 64 * 1024));
