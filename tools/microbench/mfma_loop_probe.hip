@@ -302,6 +302,86 @@ template <int L> double run_struct64(int chunks, int blocks) {
     return flops / (ms * 1e-3) / 1e12;
 }
 
+
+// AGLOBAL variant (128x128 tile): weights never touch LDS -- each wave loads its A fragments (2 dwords per lane and
+// k-step) straight from global memory (the weights are L2-resident), one 3-tap segment ahead; LDS holds the activation
+// tile only (12 dwords per thread and chunk), two barriers per chunk as before.
+__global__ __launch_bounds__(256, 2) void aglobal_kernel(float *out, const float *gw, const float *gb, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Bl = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < KC * LDB; i += 256) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
+    __syncthreads();
+    const int offA = (wave & 1) * 64 + l31, off0 = (wave >> 1) * 64 + l31, off1 = off0 + 32;
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    float bv[12];
+    for (int u = 0; u < 12; ++u) bv[u] = gb[(size_t)blockIdx.x * 65536 + u * 256 + tid];
+    float af[24], an[24];                                   // A fragments of the current / next 3-tap segment
+    auto load_seg = [&](float *dst, const float *wchunk, int g3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < KC / 2; ++s2) {
+                const float *wr = wchunk + (3 * g3 + r) * (KC * MT) + (2 * s2 + kh) * MT + offA;
+                dst[(r * 4 + s2) * 2] = wr[0];
+                dst[(r * 4 + s2) * 2 + 1] = wr[32];
+            }
+    };
+    load_seg(af, gw, 0);
+    for (int c = 0; c < chunks; ++c) {
+        const float *wc = gw + (size_t)(c & 31) * 9216, *wn = gw + (size_t)((c + 1) & 31) * 9216;
+        const float *gbc = gb + (size_t)blockIdx.x * 65536 + (size_t)((c + 1) & 7) * 4608;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 12; ++u) Bl[(u % KC) * LDB + (u / KC) * 128 + (tid & 127)] = bv[u] + (float)(tid >> 7);
+        __syncthreads();
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3) {
+            if (g3 < 2) load_seg(an, wc, g3 + 1); else load_seg(an, wn, 0);
+#pragma unroll
+            for (int u = g3; u < 12; u += 3) bv[u] = gbc[u * 256 + tid];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float *br = Bl + (3 * g3 + r) * 25 + kh * LDB;
+#pragma unroll
+                for (int s2 = 0; s2 < KC / 2; ++s2) {
+                    const float a0 = af[(r * 4 + s2) * 2], a1 = af[(r * 4 + s2) * 2 + 1], b0 = br[2*s2*LDB+off0], b1 = br[2*s2*LDB+off1];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 24; ++i) af[i] = an[i];
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) s += acc[a][b][g];
+    for (int u = 0; u < 12; ++u) s += bv[u];
+    for (int i = 0; i < 24; ++i) s += af[i];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+double run_aglobal(int chunks, int blocks, size_t lds_extra = 0) {
+    float *out, *gw, *gb;
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipMalloc(&gw, (size_t)33 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)33 * 9216 * 4 + 65536);
+    hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
+    const size_t lds = (size_t)KC * LDB * 4 + lds_extra;
+    hipFuncSetAttribute((const void *)aglobal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(aglobal_kernel, dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(aglobal_kernel, dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    hipFree(out); hipFree(gw); hipFree(gb);
+    const double flops = (double)blocks * 4 * chunks * TAPS * (KC / 2) * 4 * 4096.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
 template <int L, int OCC = 2> double run_struct(int chunks, int blocks, size_t lds_extra = 0) {
     float *out, *gw, *gb;
     hipMalloc(&out, (size_t)blocks * 256 * 4);
@@ -346,6 +426,8 @@ int main() {
     printf("struct 3 (+ 27 global prefetch loads in 3 bursts):      %.1f TFLOP/s\n", run_struct<3>(chunks, blocks));
     printf("64x256 tile: struct 0 / 1 / 2 / 3 at 2 workgroups/CU:     %.1f / %.1f / %.1f / %.1f TFLOP/s\n", run_struct64<0>(chunks, blocks),
            run_struct64<1>(chunks, blocks), run_struct64<2>(chunks, blocks), run_struct64<3>(chunks, blocks));
+    printf("A fragments from global (no W in LDS), 2 WG/CU (LDS-limited to 60 KB each): %.1f TFLOP/s\n", run_aglobal(chunks, blocks, 48 * 1024));
+    printf("A fragments from global, 1 WG/CU:                       %.1f TFLOP/s\n", run_aglobal(chunks, 256 * 6, 100 * 1024));
     printf("struct 3 at 1 workgroup/CU:                             %.1f TFLOP/s\n", run_struct<3>(chunks, 256 * 6, 48 * 1024));
     printf("pipe (4-channel halves, ping-pong LDS, 1 barrier) 2 WG/CU: %.1f TFLOP/s\n", run_pipe<2>(chunks, blocks));
     printf("pipe at 1 workgroup/CU:                                   %.1f TFLOP/s\n", run_pipe<2>(chunks, 256 * 6, 64 * 1024));
