@@ -222,11 +222,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     import torch.distributed as dist
+    # CSK_BENCH_BACKEND=gloo (debugging aid): lets several ranks share one GPU, which RCCL refuses -- used to exercise the
+    # N > 1 code path of this script on a 1-GPU box; real runs use the default, "nccl" = RCCL, one rank per GPU
+    backend = os.environ.get("CSK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     import _bootstrap
