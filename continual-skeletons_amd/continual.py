@@ -483,7 +483,7 @@ class CoStGcn(_Folded):
 
     # ---- stepping ------------------------------------------------------------------------------------
     def _cycle(self, frames):
-        """Advance by 1..4 frames (list of (N, C, V, M) tensors): data_bn, ten blocks, head.
+        """Advance by 1..MAX_CYCLE frames (list of (N, C, V, M) tensors): data_bn, ten blocks, head.
         Returns (slot, n_feat, logits): layer 10's emissions of this cycle (first output-ring slot, count;
         (None, 0) if none) and the list of predictions."""
         self._require_eval()
