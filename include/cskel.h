@@ -191,7 +191,7 @@ int csk_fuse_rank_f32(const float *const *preds, int n_streams, int use_max, int
 
 /* ------------------------------------------------------------------------------------------------
  * Native step executor ("plan"): the counterpart of co.Sequential.forward_step driving the ten continual
- * blocks and the head (models/base.py:108-122,183-190) -- one C call issues every launch of a cycle of 1..4
+ * blocks and the head (models/base.py:108-122,183-190) -- one C call issues every launch of a cycle of 1..8
  * frames (input norm, per block one GCN-stage + one multi-emission TCN-step launch, spatial pool, temporal
  * window mean, FC), with the ring-slot / stride-phase bookkeeping kept in the plan.  No allocation, no sync.
  * ------------------------------------------------------------------------------------------------ */
