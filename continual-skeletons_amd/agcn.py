@@ -89,7 +89,7 @@ class AdaptiveGraphConvolution(GraphConvolution):
         g = int(ops["embed_groups_host"][0])
         rc = native.lib().csk_tcn_step_f32(native.ptr(x), g * n_seg, g - 1, g, n_seg, native.ptr(ops["w_embed_step"]), None, 0, 0, 0,
                                            None, native.ptr(ops["b_embed"]), native.ptr(E), n_seg, 0, self.in_channels // g, e_ch,
-                                           p, g, 0, 0, 0, native.stream_of(x))
+                                           p, g, 0, 0, 0, 1, None, native.stream_of(x))
         native.check(rc, "csk_tcn_step_f32")
         adj = self._attention(E, ops, n_seg * frames, 1, v, v, p, seg_per_group=frames, e_group_stride=e_ch * p)
         o = dict(ops, ell_val=adj)

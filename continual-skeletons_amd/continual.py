@@ -76,7 +76,7 @@ class CoTemporalConvolution(TemporalConvolution):
         rc = native.lib().csk_tcn_step_f32(
             native.ptr(self._ring), self.kernel_size, self._s % self.kernel_size, 0, 1, native.ptr(ops["w"]),
             None, 0, 0, 0, None, native.ptr(ops["bias"]), native.ptr(out), 1, 0,
-            ops["c_in"], ops["c_out"], p, self.kernel_size, 0, 0, 0, native.stream_of(out))
+            ops["c_in"], ops["c_out"], p, self.kernel_size, 0, 0, 0, 1, None, native.stream_of(out))
         native.check(rc, "csk_tcn_step_f32")
         return out[:, : n * v].view(-1, n, v).permute(1, 0, 2).contiguous()
 
@@ -120,8 +120,11 @@ class CoTemporalConvolution(TemporalConvolution):
 class _BlockState:
     """Slice of the state slab owned by one block: y ring, output ring, (optionally own) input ring, counters."""
 
-    def __init__(self, c_in, c_out, k, p, device, xin=None):
+    def __init__(self, c_in, c_out, k, p, device, xin=None, ksplit=1):
         self.p = p
+        self.ksplit = ksplit
+        # split-K scratch of the TCN step (latency mode): raw partial sums of up to MAX_CYCLE emissions
+        self.partial = torch.empty((MAX_CYCLE * ksplit, c_out, p), device=device, dtype=torch.float32) if ksplit > 1 else None
         self.y = torch.zeros((YRING, c_out, p), device=device, dtype=torch.float32)
         self.out = torch.zeros((HIST, c_out, p), device=device, dtype=torch.float32)
         self.owns_xin = xin is None
@@ -208,8 +211,22 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
     # ---- persistent state --------------------------------------------------------------------------
     def bind_state(self, p: int, device, xin: Optional[torch.Tensor] = None) -> _BlockState:
         """(Re)allocate this block's slab slice for P positions; ``xin`` = upstream block's output ring."""
-        self._state = _BlockState(self.in_channels, self.out_channels, self.kernel_size, p, device, xin)
+        self._state = _BlockState(self.in_channels, self.out_channels, self.kernel_size, p, device, xin,
+                                  ksplit=self._pick_ksplit(p))
         return self._state
+
+    split_k = 0     # 0: no split-K; n > 1: latency mode -- up to n channel ranges per tile when a launch is too small
+
+    def _pick_ksplit(self, p: int) -> int:
+        """Split-K factor of the TCN step for a slab of p positions: only when the launch would otherwise hold fewer
+        than 64 workgroups (a handful of streams), at least two 8-channel chunks per split."""
+        if self.split_k <= 1:
+            return 1
+        mt = 128 if self.out_channels % 128 == 0 else 64
+        tiles = -(-p // (16384 // mt)) * (-(-self.out_channels // mt))
+        if tiles >= 64:
+            return 1
+        return max(1, min(self.split_k, 16, (-(-self.out_channels // 8)) // 2))
 
     def clean_state(self):
         if self._state is not None:
@@ -249,7 +266,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             native.ptr(st.xin) if mode else None, HIST, (first - lag) % HIST, self.stride,
             native.ptr(ops["w_res"]), native.ptr(ops["bias"]), native.ptr(st.out), HIST, slot0,
             self.out_channels, self.out_channels, p, k, mode, self.in_channels if mode else 0, 1,
-            native.stream_of(st.y))
+            st.ksplit, native.ptr(st.partial) if st.partial is not None else None, native.stream_of(st.y))
         st.e += n_emit
         return slot0, n_emit
 
@@ -398,6 +415,16 @@ class CoStGcn(_Folded):
         self._frames = self._feats = 0
         self._build_plan(device)
 
+    def set_latency_mode(self, split_k: int = 8):
+        """Few-stream operation (one camera, a handful of streams): the TCN step of a block then holds one workgroup
+        per tile that walks all 9*C/8 K-chunks alone (123 us at C = 256).  With ``split_k`` > 1 such launches cut the
+        channel axis into up to ``split_k`` ranges computed by separate workgroups and summed in a fixed order
+        (csk_tcn_step_f32 ``ksplit``); launches that fill the GPU anyway are left alone.  Results differ from the
+        default by fp32 summation order only.  Takes effect from a clean state (the slab is re-bound)."""
+        for i in range(10):
+            self.layers[f"layer{i + 1}"].split_k = int(split_k)
+        self._n = None
+
     # ---- native executor ---------------------------------------------------------------------------
     def _weights_version(self):
         return tuple(t._version for t in self._all_tensors)
@@ -420,6 +447,8 @@ class CoStGcn(_Folded):
             L.tcn_w, L.tcn_bias = t["w"].data_ptr(), t["bias"].data_ptr()
             L.tcn_w_res = t["w_res"].data_ptr() if t["w_res"] is not None else None
             L.y_ring, L.out_ring = st.y.data_ptr(), st.out.data_ptr()
+            L.tcn_ksplit = st.ksplit
+            L.tcn_partial = st.partial.data_ptr() if st.partial is not None else None
         ops = self._packed_ops(device)
         fcw, fcb = self.fc.weight.detach(), self.fc.bias.detach()
         keep += [ops, fcw, fcb]

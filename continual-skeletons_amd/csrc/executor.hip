@@ -35,7 +35,8 @@ extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *lay
         const csk_co_layer &l = layers[i];
         if (l.c_in <= 0 || l.c_out <= 0 || l.stride < 1 || l.stride > 2 || !l.gcn_w || !l.gcn_bias || !l.ell_src ||
             !l.ell_val || !l.tcn_w || !l.tcn_bias || !l.y_ring || !l.out_ring ||
-            (l.res_kind == CSK_RES_CONV && !l.tcn_w_res) || (i > 0 && l.c_in != layers[i - 1].c_out)) {
+            (l.res_kind == CSK_RES_CONV && !l.tcn_w_res) || (i > 0 && l.c_in != layers[i - 1].c_out) ||
+            (l.tcn_ksplit > 1 && !l.tcn_partial)) {
             snprintf(csk_err_buf(), 256, "co_plan_create: bad layer %d", i);
             return nullptr;
         }
@@ -117,7 +118,8 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
     const int rc = csk_tcn_step_f32(l.y_ring, CSK_CO_YRING, (int)(first % CSK_CO_YRING), l.stride, ne, l.tcn_w,
                                     l.res_kind ? xin : nullptr, CSK_CO_HIST, (int)((first - LAG) % CSK_CO_HIST), l.stride,
                                     l.tcn_w_res, l.tcn_bias, l.out_ring, CSK_CO_HIST, *slot0, l.c_out, l.c_out, P, K,
-                                    l.res_kind, l.res_kind ? l.c_in : 0, 1, stream);
+                                    l.res_kind, l.res_kind ? l.c_in : 0, 1, l.tcn_ksplit > 1 ? l.tcn_ksplit : 1, l.tcn_partial,
+                                    stream);
     if (rc) return rc;
     c.e += ne;
     *n_emit = ne;

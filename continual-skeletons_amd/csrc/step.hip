@@ -64,10 +64,14 @@ struct StepParams {
     int res_mode, Cres, CresPad, relu;
     int xres_slots, xres_slot0, xres_step, out_slots, out_slot0;
     int fast_epi;      // P fits the 32-bit lane byte offsets of the scalar-base epilogue addressing
+    int ksplit, cper;  // split-K (latency mode): grid.z = emissions * ksplit, split ks covers channels [ks*cper, ..+cper)
+    float *part;       // and writes raw partial sums to part[(emission*ksplit + ks)][Cout][P]; 1 = off
     int64_t P;
 };
 
-template <int MT>
+// SPLIT = false is the throughput kernel; the split-K form is a separate instantiation so that its extra index
+// arithmetic costs the default path nothing (it cost 1.9 % of the online throughput as a run-time switch).
+template <int MT, bool SPLIT>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
@@ -82,16 +86,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     const int64_t P = p.P;
     // emission j of this launch (blockIdx.z): newest frame in slot head + j*head_step, residual frame in
     // xres slot xres_slot0 + j*xres_step, output into out slot out_slot0 + j (all modulo their ring depths)
-    const int j = blockIdx.z;
+    constexpr bool split = SPLIT;
+    const int ks = split ? (int)blockIdx.z % p.ksplit : 0;
+    const int j = split ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z;
+    const int cb = ks * p.cper;                               // first channel of this split
+    const int Cl = split ? min(p.C - cb, p.cper) : p.C;       // its channels (<= 0: padding-only split, sums stay zero)
+    const int CpadL = split ? min(p.Cpad - cb, p.cper) : p.Cpad;
     const int head = (p.head + j * p.head_step) % p.slots;
     const float *xres = p.xres + (int64_t)((p.xres_slot0 + j * p.xres_step) % p.xres_slots) * p.Cres * P;
-    float *out = p.out + (int64_t)((p.out_slot0 + j) % p.out_slots) * p.Cout * P;
+    float *out = split ? p.part + (int64_t)(j * p.ksplit + ks) * p.Cout * P
+                       : p.out + (int64_t)((p.out_slot0 + j) % p.out_slots) * p.Cout * P;
     const float *slot_base[9];              // uniform: tap r reads ring slot (head - (K-1) + r) mod slots
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
         int slot = (head - (p.K - 1) + min(r, p.K - 1)) % p.slots;
         if (slot < 0) slot += p.slots;
-        slot_base[r] = p.ring + (int64_t)slot * p.C * P + p0;
+        slot_base[r] = p.ring + ((int64_t)slot * p.C + cb) * P + p0;
     }
 
     f32x16 acc[2][2];
@@ -108,14 +118,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     RingStage<NT> rs;
     // ---- phase 1: temporal conv over the ring
     {
-        const float *wbase = p.w + m0;
+        const float *wbase = p.w + m0 + (size_t)cb * p.Mpad;
         ws.setup(p.K, p.Cpad, p.Mpad, tid);
         rs.setup(p0, P, tid);
         ws.issue(wbase);
-        rs.issue(slot_base, p.K, p.C, P, 0);
+        rs.issue(slot_base, p.K, Cl, P, 0);
         const int t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
         int c0 = 0;
-        for (; c0 + KC < p.Cpad; c0 += KC) {
+        for (; c0 + KC < CpadL; c0 += KC) {
             __syncthreads();
             ws.commit(Wl);
             rs.commit(Bl);
@@ -124,19 +134,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
             const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
 #pragma unroll
             for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
-            rs.template issue_third<0>(slot_base, p.K, p.C, P, c0 + KC);
+            rs.template issue_third<0>(slot_base, p.K, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
             mfma_taps<MT>(Wl, Bl, 0, t1, NT, KC * NT, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
-            rs.template issue_third<1>(slot_base, p.K, p.C, P, c0 + KC);
+            rs.template issue_third<1>(slot_base, p.K, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
             if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NT, KC * NT, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
-            rs.template issue_third<2>(slot_base, p.K, p.C, P, c0 + KC);
+            rs.template issue_third<2>(slot_base, p.K, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
             if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
         mfma_chunk<MT>(Wl, Bl, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
     }
     // ---- phase 2: 1x1 residual conv on the delayed block input (CoTempConv k=1 + co.Delay, base.py:424-441)
-    if (p.res_mode == CSK_RES_CONV) {
+    if (p.res_mode == CSK_RES_CONV && ks == 0) {
         slot_base[0] = xres + p0;
         const float *wbase = p.wres + m0;
         ws.setup(1, p.CresPad, p.Mpad, tid);
@@ -169,7 +179,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     // ---- epilogue: + bias (+ identity residual), ReLU, stores.  Same scheme as tcn_stage_kernel: on full tiles the row
     // base pointers are wave-uniform (scalar unit) and every access carries one 32-bit lane byte offset;
     // v_permlane32_swap pairs the ni = 0 / 1 registers so that a store instruction writes one 256-B row segment.
-    const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    // (split-K: raw partial sums -- bias, identity residual and ReLU are applied by step_reduce_kernel)
+    const bool ident = !split && p.res_mode == CSK_RES_IDENTITY;
+    const bool relu = !split && p.relu;
     const int rbase = m0 + wm * 64;
     const bool full = p.fast_epi && m0 + MT <= p.Cout;
     const unsigned kh4 = 4u * (unsigned)kh;
@@ -178,7 +190,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) bv[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+            for (int g = 0; g < 16; ++g)
+                bv[mi][g] = split ? 0.f : ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const unsigned lo = 4u * (kh4 * (unsigned)P + (unsigned)min((int64_t)(p0 + wn * 64 + ni * 32 + l31), P - 1));
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+            for (int g = 0; g < 16; ++g) bv[mi][g] = split ? 0.f : p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int64_t qc = min((int64_t)(p0 + wn * 64 + ni * 32 + l31), P - 1);
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
         for (int g = 0; g < 16; ++g) {
             float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
             float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
-            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
             acc[mi][0][g] = __uint_as_float(sw[0]);            // row rbase + mi*32 + (g&3) + 8(g>>2), column qb
             acc[mi][1][g] = __uint_as_float(sw[1]);            // row + 4
@@ -242,6 +255,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
                 if (qv && row0 + 4 < p.Cout) out[(int64_t)(row0 + 4) * P + qb] = acc[mi][1][g];
             }
     }
+}
+
+// split-K reduction: out_j[co][p] = ReLU?( sum_ks part[j*ksplit + ks][co][p] (fixed order) + bias[co] + identity residual )
+__global__ __launch_bounds__(256) void step_reduce_kernel(const StepParams p) {
+    const int64_t P = p.P, P4 = P / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // (co, p4)
+    if (i >= (int64_t)p.Cout * P4) return;
+    const int co = (int)(i / P4);
+    const int64_t q = (i - (int64_t)co * P4) * 4;
+    const int j = blockIdx.y;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < p.ksplit; ++ks)
+        s += *reinterpret_cast<const f32x4 *>(p.part + ((int64_t)(j * p.ksplit + ks) * p.Cout + co) * P + q);
+    s += p.bias[co];
+    if (p.res_mode == CSK_RES_IDENTITY) {
+        const float *xres = p.xres + (int64_t)((p.xres_slot0 + j * p.xres_step) % p.xres_slots) * p.Cres * P;
+        s += *reinterpret_cast<const f32x4 *>(xres + (int64_t)co * P + q);
+    }
+    if (p.relu) { s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f); }
+    float *out = p.out + (int64_t)((p.out_slot0 + j) % p.out_slots) * p.Cout * P;
+    *reinterpret_cast<f32x4 *>(out + (int64_t)co * P + q) = s;
 }
 
 // feat[n, c] = mean over the M*V positions of stream n in a channel-major frame h (C, P): one wave per (n, c)
@@ -280,8 +314,10 @@ __global__ void co_window_mean_kernel(const float *__restrict__ ring, float *__r
 extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head_step, int n_emit, const float *w,
                                 const float *x_res, int x_res_slots, int x_res_slot0, int x_res_step,
                                 const float *w_res, const float *bias, float *out, int out_slots, int out_slot0,
-                                int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, void *stream) {
+                                int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, int ksplit,
+                                float *partial, void *stream) {
     if (!ring || !w || !bias || !out) CSK_FAIL("tcn_step: null pointer");
+    if (ksplit < 1 || ksplit > 16 || (ksplit > 1 && !partial)) CSK_FAIL("tcn_step: ksplit must be in [1, 16] and needs a partial-sum buffer");
     if (c <= 0 || c_out <= 0 || P < 4 || (P & 3)) CSK_FAIL("tcn_step: bad dims (P must be a positive multiple of 4)");
     if (k < 1 || k > 9 || slots < k || head < 0 || head >= slots) CSK_FAIL("tcn_step: bad k/slots/head");
     if (n_emit < 1 || n_emit > 64 || head_step < 0 || out_slots < n_emit || out_slot0 < 0 || out_slot0 >= out_slots)
@@ -303,17 +339,24 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     p.fast_epi = P < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
     p.xres_slots = x_res ? x_res_slots : 1; p.xres_slot0 = x_res ? x_res_slot0 : 0; p.xres_step = x_res_step;
     p.out_slots = out_slots; p.out_slot0 = out_slot0;
+    // split-K: every split owns >= 1 real channel; fewer splits than asked for if the channel count does not allow more
+    p.cper = round_up((p.Cpad + ksplit - 1) / ksplit, KC);
+    p.ksplit = ksplit > 1 ? (c + p.cper - 1) / p.cper : 1;
+    p.part = partial;
+    if (p.ksplit > 1 && ((uintptr_t)partial & 15)) CSK_FAIL("tcn_step: partial-sum buffer must be 16-byte aligned");
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     const size_t lds = (size_t)(9 * KC * MT + 9 * KC * NT) * sizeof(float);   // always 9 taps (73.7 KB)
-    dim3 grid((unsigned)((P + NT - 1) / NT), p.Mpad / MT, n_emit);
+    dim3 grid((unsigned)((P + NT - 1) / NT), p.Mpad / MT, n_emit * p.ksplit);
     hipStream_t s = (hipStream_t)stream;
-    if (big) {
-        if (const int e = csk_ensure_lds((const void *)tcn_step_kernel<128>, lds)) return e;
-        hipLaunchKernelGGL(tcn_step_kernel<128>, grid, dim3(NTHREADS), lds, s, p);
-    } else {
-        if (const int e = csk_ensure_lds((const void *)tcn_step_kernel<64>, lds)) return e;
-        hipLaunchKernelGGL(tcn_step_kernel<64>, grid, dim3(NTHREADS), lds, s, p);
+    void (*kern)(StepParams) = p.ksplit > 1 ? (big ? tcn_step_kernel<128, true> : tcn_step_kernel<64, true>)
+                                            : (big ? tcn_step_kernel<128, false> : tcn_step_kernel<64, false>);
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, p);
+    if (p.ksplit > 1) {
+        if (const int e = (int)hipGetLastError()) return e;
+        const int64_t work = (int64_t)c_out * (P / 4);
+        hipLaunchKernelGGL(step_reduce_kernel, dim3((unsigned)((work + 255) / 256), n_emit), dim3(256), 0, s, p);
     }
     return (int)hipGetLastError();
 }

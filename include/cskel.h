@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 6
+#define CSK_ABI_VERSION 7
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -162,11 +162,16 @@ int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, i
  *         (x_res_slot0 + j*x_res_step) mod x_res_slots = the input delayed by (k-1)/2 frames (co.Delay).
  *  out    ring [out_slots][c_out][P]; emission j is written to slot (out_slot0 + j) mod out_slots.
  *  All ring bases 16-byte aligned, P % 4 == 0.
+ *  ksplit > 1 (latency mode for few streams, where one workgroup per tile would walk the whole K loop alone): the
+ *  channel axis is cut into up to ksplit ranges computed by separate workgroups into `partial`
+ *  ([n_emit * ksplit][c_out][P] floats, 16-byte aligned) and summed in a fixed order by a second kernel that also
+ *  applies bias / identity residual / ReLU.  Results differ from ksplit = 1 by fp32 summation order only.
  */
 int csk_tcn_step_f32(const float *ring, int slots, int head, int head_step, int n_emit, const float *w,
                      const float *x_res, int x_res_slots, int x_res_slot0, int x_res_step,
                      const float *w_res, const float *bias, float *out, int out_slots, int out_slot0,
-                     int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, void *stream);
+                     int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, int ksplit, float *partial,
+                     void *stream);
 
 /* spatial_pool of CoModelBase (models/base.py:84) on a channel-major frame: feat[n, c] = mean of the MV = M*V
  * positions of stream n.  h (C, P); feat (N, C). */
@@ -202,13 +207,14 @@ int csk_fuse_rank_f32(const float *const *preds, int n_streams, int use_max, int
 typedef struct csk_co_layer {
     int32_t c_in, c_out, stride, res_kind;   /* res_kind: CSK_RES_NONE / IDENTITY / CONV (block residual) */
     int32_t gcn_res_mode, ell_w, ell_cnt[3];
-    int32_t pad_;
+    int32_t tcn_ksplit;                      /* split-K of the TCN step (csk_tcn_step_f32); 1 = off               */
     const float *gcn_w, *gcn_bias;           /* packed operands of csk_gcn_stage_f32                       */
     const int32_t *ell_src;
     const float *ell_val;
     const float *tcn_w, *tcn_w_res, *tcn_bias; /* packed operands of csk_tcn_step_f32                      */
     float *y_ring;                           /* [CSK_CO_YRING][c_out][P]                                   */
     float *out_ring;                         /* [CSK_CO_HIST][c_out][P]; input history of the next layer   */
+    float *tcn_partial;                      /* [CSK_CO_MAX_CYCLE * tcn_ksplit][c_out][P] or NULL (tcn_ksplit == 1) */
 } csk_co_layer;
 
 typedef struct csk_co_plan csk_co_plan;

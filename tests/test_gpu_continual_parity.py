@@ -285,3 +285,51 @@ def test_update_state_false_peeks_without_advancing():
             assert (got is None) == (want is None) == (peek is None)
             if want is not None:
                 assert torch.equal(got, want) and torch.equal(peek, want), t
+
+
+@pytest.mark.parametrize("native_plan", [True, False])
+def test_latency_mode_split_k_matches_oracle_and_default(native_plan):
+    """set_latency_mode (split-K in the TCN steps for a handful of streams): same predictions as the oracle and as
+    the default path up to fp32 summation order; per-frame stepping and 4-frame cycles stay bitwise equal to each
+    other; a slab that fills the GPU is left on the default path (bitwise equal to it)."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:2, :, :120].to(DEV)
+    nets = {}
+    for mode in ("default", "latency", "latency_cycles"):
+        co = pkg.CoStGcn(A, pool_size=4, pool_padding=1).eval()
+        co.use_native_plan = native_plan
+        co.load_state_dict(sd, strict=True)
+        co = co.to(DEV)
+        if mode != "default":
+            co.set_latency_mode(8)
+        nets[mode] = co
+    outs = {m: [] for m in nets}
+    for t in range(120):
+        f = x[:, :, t].contiguous()
+        for m in ("default", "latency"):
+            r = nets[m].forward_step(f)
+            if r is not None:
+                outs[m].append(r)
+    for t in range(0, 120, 4):
+        outs["latency_cycles"] += nets["latency_cycles"].forward_cycle([x[:, :, t + f].contiguous() for f in range(4)])
+    assert len(outs["default"]) == len(outs["latency"]) == len(outs["latency_cycles"]) >= 8
+    assert nets["latency"].layers["layer9"]._state.ksplit > 1 and nets["default"].layers["layer9"]._state.ksplit == 1
+    for d, l, c in zip(outs["default"], outs["latency"], outs["latency_cycles"]):
+        assert max_err(l.cpu(), d.cpu()) <= TOL * max(1.0, float(d.abs().max()))
+        assert torch.equal(l, c)
+    orc = o.CoStGcnOracle(sd, pool_size=4, pool_padding=1)
+    want = [r for r in (orc.forward_step(x[:, :, t].cpu()) for t in range(120)) if r is not None]
+    for l, w in zip(outs["latency"], want):
+        assert max_err(l.cpu(), w) <= TOL * max(1.0, float(w.abs().max()))
+    # a full slab: latency mode must not change a bit
+    big = [pkg.CoStGcn(A, pool_size=2, pool_padding=0).eval() for _ in range(2)]
+    for b in big:
+        b.use_native_plan = native_plan
+        b.load_state_dict(sd, strict=True)
+    big = [b.to(DEV) for b in big]
+    big[1].set_latency_mode(8)
+    frames = torch.rand((88, 700, 3, 25, 2), device=DEV)
+    for t in range(88):
+        r0, r1 = big[0].forward_step(frames[t]), big[1].forward_step(frames[t])
+        assert (r0 is None) == (r1 is None) and (r0 is None or torch.equal(r0, r1))
+    assert all(big[1].layers[f"layer{i + 1}"]._state.ksplit == 1 for i in range(10))
