@@ -415,14 +415,20 @@ class CoStGcn(_Folded):
         self._frames = self._feats = 0
         self._build_plan(device)
 
-    def set_latency_mode(self, split_k: int = 8):
+    _plan_graphs = False
+
+    def set_latency_mode(self, split_k: int = 8, graphs: bool = False):
         """Few-stream operation (one camera, a handful of streams): the TCN step of a block then holds one workgroup
         per tile that walks all 9*C/8 K-chunks alone (123 us at C = 256).  With ``split_k`` > 1 such launches cut the
         channel axis into up to ``split_k`` ranges computed by separate workgroups and summed in a fixed order
         (csk_tcn_step_f32 ``ksplit``); launches that fill the GPU anyway are left alone.  Results differ from the
-        default by fp32 summation order only.  Takes effect from a clean state (the slab is re-bound)."""
+        default by fp32 summation order only.  ``graphs``: the native executor replays the block launches of a frame
+        from hipGraphs (csk_co_plan_set_graphs; bit-identical, but measured SLOWER than eager launches on ROCm 7.2:
+        0.41 vs 0.36 ms per frame-step, so it is off by default).  Takes effect from a clean state (the slab is
+        re-bound)."""
         for i in range(10):
             self.layers[f"layer{i + 1}"].split_k = int(split_k)
+        self._plan_graphs = bool(graphs)
         self._n = None
 
     # ---- native executor ---------------------------------------------------------------------------
@@ -473,6 +479,8 @@ class CoStGcn(_Folded):
             raise RuntimeError("csk_co_plan_create: " + native.lib().csk_last_error().decode())
         self.__dict__["_plan"] = plan
         self.__dict__["_plan_keep"] = (keep, self._weights_version())
+        if self._plan_graphs:
+            native.check(native.lib().csk_co_plan_set_graphs(plan, 1), "csk_co_plan_set_graphs")
 
     def _refresh_plan_weights(self, device):
         """Weights were reloaded / edited in place: refold and hand the new operands to the plan; the

@@ -34,6 +34,7 @@ SIGNATURES = {
     "csk_co_plan_update_weights": [_p, _i, _p, _p, _p, _p, _p],
     "csk_co_plan_reset": [_p],
     "csk_co_plan_counters": [_p, C.POINTER(C.c_int64), _i, _i],
+    "csk_co_plan_set_graphs": [_p, _i],
     "csk_co_plan_cycle": [_p, _p, _i, _p, _p, _p, _p, _p],
 }
 RESTYPES = {"csk_co_plan_create": C.c_void_p, "csk_co_plan_destroy": None, "csk_co_plan_reset": None}

@@ -235,6 +235,12 @@ void csk_co_plan_reset(csk_co_plan *plan);
  * n = 2 + 2*n_layers.  forward_step(x, update_state=False) (models/base.py:183-185) = read, cycle, write back: a
  * step only overwrites ring slots whose content is older than any window, so the counters are the whole state. */
 int csk_co_plan_counters(csk_co_plan *plan, int64_t *buf, int n, int set);
+/* latency mode: replay the block launches of a cycle from hipGraphs.  The launch sequence and all kernel arguments
+ * of a cycle depend only on (r, per block: frames mod 16, emissions mod 16, warm-up state) -- 64 states in steady
+ * per-frame stepping; a state runs eagerly on its first visit, is captured on the second and replayed from then on.
+ * The blocks then run on a stream owned by the plan, fenced against the caller's stream by events; input
+ * normalisation and the head stay ordinary launches.  Same kernels, same arguments: bit-identical results. */
+int csk_co_plan_set_graphs(csk_co_plan *plan, int enable);
 /* Advance by r = 1..CSK_CO_MAX_CYCLE frames, frames[i] = (N, C, V, M) device pointers.  On return
  * *last_slot / *n_feat describe the last layer's emissions of this cycle (slot of the first, count) and
  * *n_logits how many predictions were written to `logits` ([CSK_CO_MAX_CYCLE][N][classes], slice j = prediction j). */
