@@ -481,16 +481,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-// pick the <MT, NJ> instantiation, raise its dynamic-LDS cap, launch
-template <typename P, typename K>
-static int launch_stage(bool big, bool small_span, dim3 grid, size_t lds, hipStream_t s, const P &p, K k128a, K k128b,
-                        K k64a, K k64b) {
-    K k = big ? (small_span ? k128a : k128b) : (small_span ? k64a : k64b);
-    if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
-    hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds, s, p);
-    return (int)hipGetLastError();
-}
-
 extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
                                  const float *ell_val, const int32_t *ell_cnt, int ell_w, int64_t adj_seg_stride,
                                  int adj_per_frame,
@@ -547,7 +537,13 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     }
     const int nj = (p.ldb + 63) / 64;
     if (nj > 14) CSK_FAIL("gcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
-    return launch_stage(big, nj <= 9, grid, lds, (hipStream_t)stream, p,
-                        gcn_stage_kernel<128, 9>, gcn_stage_kernel<128, 14>, gcn_stage_kernel<64, 9>, gcn_stage_kernel<64, 14>);
+    // activation staging sweeps per row: whole frames of the tile only (no temporal halo), i.e. <= 192 positions for
+    // 128-wide and <= 320 for 256-wide tiles at V <= 64 -- 3 / 5 sweeps; the 9 / 14-sweep forms remain as fall-backs
+    void (*kern)(GcnParams) =
+        big ? (nj <= 3 ? gcn_stage_kernel<128, 3> : nj <= 9 ? gcn_stage_kernel<128, 9> : gcn_stage_kernel<128, 14>)
+            : (nj <= 5 ? gcn_stage_kernel<64, 5> : nj <= 9 ? gcn_stage_kernel<64, 9> : gcn_stage_kernel<64, 14>);
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
 }
 
