@@ -23,6 +23,7 @@ struct GcnParams {
     int lds_frames;      // frames of adjacency staged per workgroup in that mode
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup of the sparse kernel
     int fast_epi;        // channel strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
+    int no_pair_reads;   // diagnostic (CSK_NO_PAIR_READS): general kernel aggregates with scalar LDS reads for even V too
 };
 
 template <int MT, int NJ>
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
     }
     // dense mode: every subset lists all V source joints in order (src[e] == e), as the A-GCN host code builds it
     const bool dense_all = p.dense;
+    const bool csk_odd_path = p.no_pair_reads;      // diagnostic: scalar LDS reads also for even V
     // aggregation-pass coordinates of this thread: one column, KPT channels
     const int aj = tid % NT, ak0 = (tid / NT) * KPT;
     const int aq = min(q0 + aj, Q - 1);
@@ -108,7 +110,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
             for (int kk = 0; kk < KPT; ++kk) s0[kk] = s1[kk] = s2[kk] = 0.f;
             const int fo = p.adj_per_frame ? (at - ta) * adj_n : 0;          // this column's frame matrix
             const int eb0 = fo + aw * EW, eb1 = fo + (V + aw) * EW, eb2 = fo + (2 * V + aw) * EW;
-            for (int e = 0; e < V; ++e) {
+            int e = 0;
+            if ((V & 1) == 0 && !csk_odd_path) {
+                // even joint count (Kinetics V = 18): every row / adjacency column starts 8-byte aligned, so two source
+                // joints are fetched per LDS instruction (the pass is LDS-issue bound: 3 + KPT reads per 3*KPT FMAs)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                for (; e < V; e += 2) {
+                    const f32x2 v0 = *reinterpret_cast<const f32x2 *>(Lv + eb0 + e), v1 = *reinterpret_cast<const f32x2 *>(Lv + eb1 + e),
+                                v2 = *reinterpret_cast<const f32x2 *>(Lv + eb2 + e);
+#pragma unroll
+                    for (int kk = 0; kk < KPT; ++kk) {
+                        const f32x2 xv = *reinterpret_cast<const f32x2 *>(bx + kk * p.ldb + e);
+                        s0[kk] = fmaf(v0[1], xv[1], fmaf(v0[0], xv[0], s0[kk]));
+                        s1[kk] = fmaf(v1[1], xv[1], fmaf(v1[0], xv[0], s1[kk]));
+                        s2[kk] = fmaf(v2[1], xv[1], fmaf(v2[0], xv[0], s2[kk]));
+                    }
+                }
+            }
+            for (; e < V; ++e) {
                 const float v0 = Lv[eb0 + e], v1 = Lv[eb1 + e], v2 = Lv[eb2 + e];
 #pragma unroll
                 for (int kk = 0; kk < KPT; ++kk) {
@@ -507,6 +526,7 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     p.dense = adj_seg_stride != 0 && ell_w == V && ell_cnt[0] == V && ell_cnt[1] == V && ell_cnt[2] == V;
     p.adj_per_frame = adj_per_frame != 0;
     p.stamps = csk_diag_stamps();
+    p.no_pair_reads = csk_diag_flag("CSK_NO_PAIR_READS");
     p.fast_epi = x_chan_stride < (1ll << 28) && y_chan_stride < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
     if (p.adj_per_frame && !p.dense) CSK_FAIL("gcn_stage: per-frame adjacency must be dense (ell_w == V, ell_cnt == V)");
     p.vmagic = vmagic_of(V);
