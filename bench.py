@@ -191,6 +191,47 @@ def cpu_baseline_step(seed):
                 sample=f"{n} steady-state frames of one NTU-60 stream after 76 warm-up frames, oracle.CoStGcnOracle")
 
 
+def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2):
+    """BASELINE.json configs[3]: A-GCN (per-sample adaptive adjacency) clip forward and CoAGCN online step at the
+    Kinetics-400 shape (V = 18, T = 300), synthetic inputs resident in HBM, random-init weights."""
+    A, shape = pkg.kinetics_graph().A, (3, 300, 18, 2)
+    net = pkg.AGcn(A, shape, 400).eval()
+    randomise_(net, 0)
+    net = net.to(dev)
+    x = torch.rand((batch,) + shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    for _ in range(2):
+        net(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        net(x)
+    torch.cuda.synchronize()
+    clip_dt = (time.perf_counter() - t0) / 5
+    del net, x
+
+    def make():
+        co = pkg.CoAGcn(A, shape, 400).eval()
+        randomise_(co, 0)
+        return co.to(dev)
+    eng = parallel.StreamShards(make, streams, shards, dev)
+    frames = torch.rand((8, streams) + (3, 18, 2), device=dev, generator=torch.Generator(device=dev).manual_seed(8))
+    for t in range(76 + 8):
+        eng.forward_cycle([frames[t % 8]])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(12):
+        eng.forward_cycle([frames[(4 * c + f) % 8] for f in range(4)])
+    torch.cuda.synchronize()
+    step_dt = (time.perf_counter() - t0) / 12
+    del eng
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"config": "BASELINE.json configs[3], Kinetics-400 shape (3,300,18,2), fp32, synthetic, per GPU",
+            "agcn_clip": {"value": round(batch / clip_dt, 1), "unit": "clips/s", "batch": batch, "ms_per_step": round(clip_dt * 1e3, 3)},
+            "coagcn_online": {"value": round(4 * streams / step_dt, 1), "unit": "frames/s", "streams": streams,
+                              "stream_shards": shards, "frames_per_launch": 4, "ms_per_frame_step": round(step_dt / 4 * 1e3, 4)}}
+
+
 def load_traffic(name="traffic_tcn_stage.json"):
     """Per-launch HBM bytes of the dominant kernel from the committed PMC summary (profiles/), or None."""
     p = os.path.join(ROOT, "profiles", name)
@@ -351,6 +392,10 @@ def main():
                     "roofline": step_info["roofline"], "cpu_baseline": cpu_step}
         else:
             line["costgcn_online"] = step_info
+    if do_clip and do_step and world == 1:          # BASELINE.json configs[3] beside the headline numbers (per GPU)
+        gc.collect()
+        torch.cuda.empty_cache()
+        line["agcn_kinetics"] = run_config4(pkg, dev, parallel)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
