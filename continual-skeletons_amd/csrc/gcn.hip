@@ -527,7 +527,8 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     p.adj_per_frame = adj_per_frame != 0;
     p.stamps = csk_diag_stamps();
     p.no_pair_reads = csk_diag_flag("CSK_NO_PAIR_READS");
-    p.fast_epi = x_chan_stride < (1ll << 28) && y_chan_stride < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
+    // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
+    p.fast_epi = x_chan_stride < (1ll << 27) && y_chan_stride < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     if (p.adj_per_frame && !p.dense) CSK_FAIL("gcn_stage: per-frame adjacency must be dense (ell_w == V, ell_cnt == V)");
     p.vmagic = vmagic_of(V);
     const bool big = (p.Mpad % 128) == 0;

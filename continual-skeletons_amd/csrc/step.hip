@@ -336,7 +336,8 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.K = k; p.slots = slots; p.head = head; p.head_step = head_step; p.res_mode = res_mode;
     p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD); p.relu = relu; p.P = P;
-    p.fast_epi = P < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
+    // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
+    p.fast_epi = P < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     p.xres_slots = x_res ? x_res_slots : 1; p.xres_slot0 = x_res ? x_res_slot0 : 0; p.xres_step = x_res_step;
     p.out_slots = out_slots; p.out_slot0 = out_slot0;
     // split-K: every split owns >= 1 real channel; fewer splits than asked for if the channel count does not allow more

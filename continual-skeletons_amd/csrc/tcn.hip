@@ -289,7 +289,8 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
     p.stamps = csk_diag_stamps();
     p.prio = !csk_diag_flag("CSK_NOPRIO");
-    p.fast_epi = (int64_t)p.Tres * V < (1ll << 28) && (int64_t)t_out * V < (1ll << 28) && !csk_diag_flag("CSK_SLOW_EPI");
+    // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
+    p.fast_epi = (int64_t)p.Tres * V < (1ll << 27) && (int64_t)t_out * V < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     // the register staging holds <= 14 x 64 positions of an activation row; tiles whose input span (stride * frames
