@@ -8,7 +8,8 @@ import torch
 import _bootstrap, bench
 pkg = _bootstrap.load()
 from continual_skeletons_amd import parallel
-var = sys.argv[1]
+var, _, val = sys.argv[1].partition("=")
+val = val or "1"
 dev = torch.device("cuda:0")
 streams = 1024
 
@@ -27,7 +28,7 @@ res = {0: [], 1: []}
 for rnd in range(10):
     for flag in (0, 1):
         if flag:
-            os.environ[var] = "1"
+            os.environ[var] = val
         else:
             os.environ.pop(var, None)
         torch.cuda.synchronize()
@@ -38,4 +39,4 @@ for rnd in range(10):
         if rnd >= 2:
             res[flag].append(4 * streams * 12 / (time.perf_counter() - t0))
 m0, m1 = statistics.median(res[0]), statistics.median(res[1])
-print(f"online 1024 streams: default {m0:,.0f} frames/s | {var}=1 {m1:,.0f} frames/s | default/alt {m0 / m1:.4f}")
+print(f"online 1024 streams: default {m0:,.0f} frames/s | {var}={val} {m1:,.0f} frames/s | default/alt {m0 / m1:.4f}")
