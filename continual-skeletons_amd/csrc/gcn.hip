@@ -213,8 +213,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const float v0 = fmaxf(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g], 0.f);
-            const float v1 = fmaxf(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g], 0.f);
+            const float v0 = relu_nan(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g]);
+            const float v1 = relu_nan(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g]);
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
             acc[mi][0][g] = __uint_as_float(sw[0]);
             acc[mi][1][g] = __uint_as_float(sw[1]);
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const float v0 = fmaxf(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g], 0.f);
-            const float v1 = fmaxf(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g], 0.f);
+            const float v0 = relu_nan(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g]);
+            const float v1 = relu_nan(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g]);
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
             acc[mi][0][g] = __uint_as_float(sw[0]);       // row (g & 3) + 8*(g >> 2), column qb
             acc[mi][1][g] = __uint_as_float(sw[1]);       // row + 4

@@ -51,6 +51,10 @@ __device__ __forceinline__ void st_lane(float *row, unsigned byte_off, float v) 
     *reinterpret_cast<float *>(reinterpret_cast<char *>(row) + byte_off) = v;
 }
 
+// ReLU that propagates NaN like torch.relu / np.maximum (v_maximum3_f32; fmaxf would return the non-NaN operand and
+// mask corrupt activations as zeros)
+__device__ __forceinline__ float relu_nan(float v) { return __builtin_elementwise_maximum(v, 0.f); }
+
 __device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned total) {
     const unsigned q = total / 8, r = total % 8, xcd = bid % 8, k = bid / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;

@@ -12,48 +12,65 @@
 #include "mfma_core.h"
 
 // ------------------------------------------------------------------------------------------------
-// ring staging: taps*KC rows of NT positions -> Bl [taps][KC][NT]
+// ring staging: NS ring slots x KC channel rows x NP positions -> Bl [slot][KC][NP]
 // ------------------------------------------------------------------------------------------------
-// Staging slot u of a thread covers row u*RPU + tid/N4 of the [tap][kk] row space (RPU = 256/N4 rows per
-// sweep, a divisor of KC), so the TAP of slot u is the compile-time constant u*RPU/KC and only kk depends on
-// the thread: slot base pointers stay wave-uniform scalars.  Slots beyond `taps` re-stage the last tap into
-// LDS rows that are never read (the LDS tile is always sized for 9 taps).
-template <int NT>
+// A workgroup tile of NT = 16384/MT columns is E emissions x NP = NT/E positions: the E emissions of a launch cycle
+// at the same positions share all but (E-1)*head_step of their 9 ring slots, so one staged window of
+//     S = K-1 + (E-1)*head_step + 1   slots
+// serves E*K taps (E = 4: 12 slots instead of 36 -- the step analogue of the clip kernel's temporal halo), and a tap
+// of emission j is the LDS row block  j*head_step + r.
+// Staging sweep u of a thread covers row u*RPU + tid/N4 of the [slot][kk] row space (RPU = 256/N4 rows per sweep).
+// A wave covers whole rows of ONE slot in every sweep (N4 <= 64, rows per wave divide KC), so the slot of a sweep is
+// wave-uniform: slot bases stay on the scalar unit.  Rows past the window (sweep padding, K < 9) re-stage its last
+// slot into LDS rows that are never read.
+template <int NP, int NS>
 struct RingStage {
-    static constexpr int N4 = NT / 4;
-    static constexpr int RPU = NTHREADS / N4;              // rows per sweep: 8 (NT=128) or 4 (NT=256)
-    static constexpr int NB = 9 * KC / RPU;                // f32x4 per thread: 9 or 18
-    unsigned poff;                                         // clamped position offset inside the tile
-    int kbase;                                             // tid / N4
+    static constexpr int N4 = NP / 4;
+    static constexpr int RPU = NTHREADS / N4;                       // rows per sweep: 4 (NP=256) .. 16 (NP=64)
+    static constexpr int NB = (NS * KC + RPU - 1) / RPU;            // f32x4 per thread per chunk
+    static constexpr int LDS_FLOATS = NB * RPU * NP;
+    unsigned poff;                                                  // clamped position offset inside the tile
+    int krow;                                                       // tid / N4: row inside a sweep
+    int64_t soff[NB];                                               // element offset of this wave's ring slot per sweep (uniform)
     f32x4 v[NB];
     __device__ __forceinline__ void setup(int p0, int64_t P, int tid) {
-        kbase = tid / N4;
-        poff = (unsigned)min((tid % N4) * 4, (int)(P - 4 - p0));   // last legal f32x4 start relative to p0
+        krow = tid / N4;
+        poff = (unsigned)min((tid % N4) * 4, (int)(P - 4 - p0));    // last legal f32x4 start relative to p0
     }
-    // base[r] = ring + slot(r) * C * P + p0 (uniform); rows c0 + kk, channels >= C read as zero
-    __device__ __forceinline__ void issue(const float *const (&base)[9], int taps, int C, int64_t P, int c0) {
+    // window slot w lives in ring slot (first + w*step) mod slots of Cs channel rows each (computed once per phase)
+    __device__ __forceinline__ void window(int first, int step, int slots, int nwin, int Cs, int64_t P) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int tap = min((u * RPU) / KC, taps - 1);           // uniform
-            const int c = c0 + (u * RPU) % KC + kbase;
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(base[tap] + (int64_t)min(c, C - 1) * P + poff);
-            v[u] = x * (c < C ? 1.f : 0.f);
+            const int w = min((u * RPU + krow) / KC, nwin - 1);
+            const int64_t o = (int64_t)((first + w * step) % slots) * Cs * P;
+            soff[u] = ((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)o);
         }
     }
-    // slots [G*NB/3, (G+1)*NB/3): one third of the chunk (G is a literal so that register indices are static)
-    template <int G>
-    __device__ __forceinline__ void issue_third(const float *const (&base)[9], int taps, int C, int64_t P, int c0) {
+    // base = ring + p0 (uniform); rows c0 + kk, channels >= C read as zero
+    template <int U0, int U1>
+    __device__ __forceinline__ void issue_range(const float *__restrict__ base, int C, int64_t P, int c0) {
 #pragma unroll
-        for (int u = G * (NB / 3); u < (G + 1) * (NB / 3); ++u) {
-            const int tap = min((u * RPU) / KC, taps - 1);
-            const int c = c0 + (u * RPU) % KC + kbase;
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(base[tap] + (int64_t)min(c, C - 1) * P + poff);
+        for (int u = U0; u < U1; ++u) {
+            const int c = c0 + (u * RPU + krow) % KC;
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(base + soff[u] + (int64_t)min(c, C - 1) * P + poff);
             v[u] = x * (c < C ? 1.f : 0.f);
         }
     }
+    // NU = sweeps actually needed (compile-time: ceil(window_slots*KC / RPU))
+    template <int NU = NB>
+    __device__ __forceinline__ void issue(const float *__restrict__ base, int C, int64_t P, int c0) {
+        issue_range<0, (NU < NB ? NU : NB)>(base, C, P, c0);
+    }
+    // one third of the chunk's sweeps (G is a literal so that register indices are static)
+    template <int G>
+    __device__ __forceinline__ void issue_third(const float *__restrict__ base, int C, int64_t P, int c0) {
+        issue_range<G * NB / 3, (G + 1) * NB / 3>(base, C, P, c0);
+    }
+    template <int NU = NB>
     __device__ __forceinline__ void commit(float *__restrict__ Bl) const {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) *reinterpret_cast<f32x4 *>(Bl + (u * RPU + kbase) * NT + poff) = v[u];
+        for (int u = 0; u < (NU < NB ? NU : NB); ++u) *reinterpret_cast<f32x4 *>(Bl + (u * RPU + krow) * NP + poff) = v[u];
     }
 };
 
@@ -69,40 +86,43 @@ struct StepParams {
     int64_t P;
 };
 
-// SPLIT = false is the throughput kernel; the split-K form is a separate instantiation so that its extra index
-// arithmetic costs the default path nothing (it cost 1.9 % of the online throughput as a run-time switch).
-template <int MT, bool SPLIT>
+// E = emissions per workgroup tile (folded into the tile's column axis, see RingStage), HS = head_step of the launch
+// (1, or 2 for a stride-2 block; only meaningful for E > 1).  SPLIT = false is the throughput kernel; the split-K form
+// is a separate instantiation (E = 1) so that its extra index arithmetic costs the default path nothing.
+template <int MT, int E, int HS, bool SPLIT>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
     constexpr int NT = 16384 / MT;
+    constexpr int NP = NT / E;                      // positions per tile
+    constexpr int NS = 8 + (E - 1) * HS + 1;        // window slots staged per chunk (K = 9)
     constexpr int WM = MT / 64;
+    static_assert(NP >= 64, "a wave's 64 columns must belong to one emission");
+    typedef RingStage<NP, NS> Stage;
+    constexpr int NU_RES = (E * KC + Stage::RPU - 1) / Stage::RPU;      // sweeps of the residual-conv phase (E slots)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem;                       // [K][KC][MT]
-    float *Bl = smem + 9 * KC * MT;         // [9][KC][NT]  (always sized for 9 taps)
+    float *Bl = smem + 9 * KC * MT;         // [NS (+ sweep padding)][KC][NP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * MT, p0 = blockIdx.x * NT;
+    const int m0 = blockIdx.y * MT, p0 = blockIdx.x * NP;
     const int64_t P = p.P;
-    // emission j of this launch (blockIdx.z): newest frame in slot head + j*head_step, residual frame in
-    // xres slot xres_slot0 + j*xres_step, output into out slot out_slot0 + j (all modulo their ring depths)
+    // emission group of this workgroup (blockIdx.z): emissions j0 .. j0+E-1 of the launch; emission j has its newest
+    // frame in slot head + j*head_step, its residual frame in xres slot xres_slot0 + j*xres_step and goes to out slot
+    // out_slot0 + j (all modulo their ring depths)
     constexpr bool split = SPLIT;
     const int ks = split ? (int)blockIdx.z % p.ksplit : 0;
-    const int j = split ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z;
+    const int j0 = (split ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z) * E;
+    const int jw = j0 + (wn * 64) / NP;                       // emission of this wave's 64 columns (wave-uniform)
     const int cb = ks * p.cper;                               // first channel of this split
     const int Cl = split ? min(p.C - cb, p.cper) : p.C;       // its channels (<= 0: padding-only split, sums stay zero)
     const int CpadL = split ? min(p.Cpad - cb, p.cper) : p.Cpad;
-    const int head = (p.head + j * p.head_step) % p.slots;
-    const float *xres = p.xres + (int64_t)((p.xres_slot0 + j * p.xres_step) % p.xres_slots) * p.Cres * P;
-    float *out = split ? p.part + (int64_t)(j * p.ksplit + ks) * p.Cout * P
-                       : p.out + (int64_t)((p.out_slot0 + j) % p.out_slots) * p.Cout * P;
-    const float *slot_base[9];              // uniform: tap r reads ring slot (head - (K-1) + r) mod slots
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        int slot = (head - (p.K - 1) + min(r, p.K - 1)) % p.slots;
-        if (slot < 0) slot += p.slots;
-        slot_base[r] = p.ring + ((int64_t)slot * p.C + cb) * P + p0;
-    }
+    const int nwin = p.K + (E - 1) * HS;                      // window slots actually used
+    int first = (p.head + j0 * p.head_step - (p.K - 1)) % p.slots;     // ring slot of window slot 0
+    if (first < 0) first += p.slots;
+    const float *xres = p.xres + (int64_t)((p.xres_slot0 + jw * p.xres_step) % p.xres_slots) * p.Cres * P;
+    float *out = split ? p.part + (int64_t)(jw * p.ksplit + ks) * p.Cout * P
+                       : p.out + (int64_t)((p.out_slot0 + jw) % p.out_slots) * p.Cout * P;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -113,16 +133,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
     const int offA = wm * 64 + l31;
-    const int off0 = wn * 64 + l31, off1 = off0 + 32;
+    // B operand of (tap r, channel kk, this lane's column): Bl[((jl*HS + r)*KC + kk)*NP + column inside the emission]
+    const int jl = (wn * 64) / NP, cw = (wn * 64) % NP;
+    const int off0 = jl * HS * KC * NP + cw + l31, off1 = off0 + 32;
     WStage<MT> ws;
-    RingStage<NT> rs;
-    // ---- phase 1: temporal conv over the ring
+    Stage rs;
+    // ---- phase 1: temporal conv over the ring window
     {
         const float *wbase = p.w + m0 + (size_t)cb * p.Mpad;
+        const float *rbase = p.ring + (int64_t)cb * P + p0;
         ws.setup(p.K, p.Cpad, p.Mpad, tid);
         rs.setup(p0, P, tid);
         ws.issue(wbase);
-        rs.issue(slot_base, p.K, Cl, P, 0);
+        rs.window(first, 1, p.slots, nwin, p.C, P);
+        rs.issue(rbase, Cl, P, 0);
         const int t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
         int c0 = 0;
         for (; c0 + KC < CpadL; c0 += KC) {
@@ -134,46 +158,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
             const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
 #pragma unroll
             for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
-            rs.template issue_third<0>(slot_base, p.K, Cl, P, c0 + KC);
+            rs.template issue_third<0>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            mfma_taps<MT>(Wl, Bl, 0, t1, NT, KC * NT, offA, off0, off1, kh, acc);
+            mfma_taps<MT>(Wl, Bl, 0, t1, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
-            rs.template issue_third<1>(slot_base, p.K, Cl, P, c0 + KC);
+            rs.template issue_third<1>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NT, KC * NT, offA, off0, off1, kh, acc);
+            if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
-            rs.template issue_third<2>(slot_base, p.K, Cl, P, c0 + KC);
+            rs.template issue_third<2>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
+            if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         ws.commit(Wl);
         rs.commit(Bl);
         __syncthreads();
-        mfma_chunk<MT>(Wl, Bl, p.K, NT, KC * NT, offA, off0, off1, kh, acc);
+        mfma_chunk<MT>(Wl, Bl, p.K, NP, KC * NP, offA, off0, off1, kh, acc);
     }
-    // ---- phase 2: 1x1 residual conv on the delayed block input (CoTempConv k=1 + co.Delay, base.py:424-441)
+    // ---- phase 2: 1x1 residual conv on the delayed block input (CoTempConv k=1 + co.Delay, base.py:424-441): the
+    // window is the E residual frames of the tile's emissions, one "tap" each
     if (p.res_mode == CSK_RES_CONV && ks == 0) {
-        slot_base[0] = xres + p0;
         const float *wbase = p.wres + m0;
+        const float *xbase = p.xres + p0;
+        const int xfirst = (p.xres_slot0 + j0 * p.xres_step) % p.xres_slots;
+        const int offr0 = jl * KC * NP + cw + l31, offr1 = offr0 + 32;
         ws.setup(1, p.CresPad, p.Mpad, tid);
         ws.issue(wbase);
-        rs.issue(slot_base, 1, p.Cres, P, 0);
+        rs.window(xfirst, p.xres_step, p.xres_slots, E, p.Cres, P);
+        rs.template issue<NU_RES>(xbase, p.Cres, P, 0);
         for (int c0 = 0; c0 < p.CresPad; c0 += KC) {
             __syncthreads();
             ws.commit(Wl);
-            rs.commit(Bl);
+            rs.template commit<NU_RES>(Bl);
             __syncthreads();
             if (c0 + KC < p.CresPad) {
                 ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
-                rs.issue(slot_base, 1, p.Cres, P, c0 + KC);
+                rs.template issue<NU_RES>(xbase, p.Cres, P, c0 + KC);
             }
-            mfma_chunk<MT>(Wl, Bl, 1, NT, KC * NT, offA, off0, off1, kh, acc);
+            mfma_chunk<MT>(Wl, Bl, 1, NP, KC * NP, offA, offr0, offr1, kh, acc);
         }
     }
     // ---- epilogue: + bias (+ identity residual), ReLU, stores.  Same scheme as tcn_stage_kernel: on full tiles the row
@@ -185,6 +213,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     const int rbase = m0 + wm * 64;
     const bool full = p.fast_epi && m0 + MT <= p.Cout;
     const unsigned kh4 = 4u * (unsigned)kh;
+    const int pw = p0 + cw;                                   // first position of this wave's columns
     float bv[2][16], rv[2][2][16];
     if (full) {
 #pragma unroll
@@ -194,7 +223,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
                 bv[mi][g] = split ? 0.f : ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const unsigned lo = 4u * (kh4 * (unsigned)P + (unsigned)min((int64_t)(p0 + wn * 64 + ni * 32 + l31), P - 1));
+            const unsigned lo = 4u * (kh4 * (unsigned)P + (unsigned)min((int64_t)(pw + ni * 32 + l31), P - 1));
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -210,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
             for (int g = 0; g < 16; ++g) bv[mi][g] = split ? 0.f : p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int64_t qc = min((int64_t)(p0 + wn * 64 + ni * 32 + l31), P - 1);
+            const int64_t qc = min((int64_t)(pw + ni * 32 + l31), P - 1);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -226,12 +255,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
         for (int g = 0; g < 16; ++g) {
             float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
             float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
-            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            if (relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
             acc[mi][0][g] = __uint_as_float(sw[0]);            // row rbase + mi*32 + (g&3) + 8(g>>2), column qb
             acc[mi][1][g] = __uint_as_float(sw[1]);            // row + 4
         }
-    const int64_t qb = (int64_t)p0 + wn * 64 + lane;
+    const int64_t qb = (int64_t)pw + lane;
     const bool qv = qb < P;
     if (full) {
         if (qv) {
@@ -273,7 +302,7 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const StepParams p) {
         const float *xres = p.xres + (int64_t)((p.xres_slot0 + j * p.xres_step) % p.xres_slots) * p.Cres * P;
         s += *reinterpret_cast<const f32x4 *>(xres + (int64_t)co * P + q);
     }
-    if (p.relu) { s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f); }
+    if (p.relu) { s[0] = relu_nan(s[0]); s[1] = relu_nan(s[1]); s[2] = relu_nan(s[2]); s[3] = relu_nan(s[3]); }
     float *out = p.out + (int64_t)((p.out_slot0 + j) % p.out_slots) * p.Cout * P;
     *reinterpret_cast<f32x4 *>(out + (int64_t)co * P + q) = s;
 }
@@ -347,11 +376,25 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     if (p.ksplit > 1 && ((uintptr_t)partial & 15)) CSK_FAIL("tcn_step: partial-sum buffer must be 16-byte aligned");
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
-    const size_t lds = (size_t)(9 * KC * MT + 9 * KC * NT) * sizeof(float);   // always 9 taps (73.7 KB)
-    dim3 grid((unsigned)((P + NT - 1) / NT), p.Mpad / MT, n_emit * p.ksplit);
+    // emissions folded into a workgroup tile: the largest E in {4, 2, 1} that divides n_emit and leaves >= 64 positions
+    // per emission (a wave's 64 columns must belong to one emission); stride-2 launches only as 128-row tiles of two
+    // emissions (the only stride-2 shapes of the ST-GCN stack); split-K and the E = 1 form use the plain tile.
+    int E = 1;
+    if (p.ksplit == 1 && k == 9 && !csk_diag_flag("CSK_STEP_NOFOLD")) {
+        if (!big && head_step == 1) E = (n_emit % 4 == 0) ? 4 : (n_emit % 2 == 0) ? 2 : 1;
+        if (big && head_step <= 2 && head_step >= 1) E = (n_emit % 2 == 0) ? 2 : 1;
+    }
+    const int NP = NT / E;
+    void (*kern)(StepParams);
+    size_t stage_floats;
+#define CSK_PICK(MT_, E_, HS_, SP_) (kern = tcn_step_kernel<MT_, E_, HS_, SP_>, stage_floats = RingStage<16384 / MT_ / E_, 8 + (E_ - 1) * HS_ + 1>::LDS_FLOATS)
+    if (p.ksplit > 1) big ? CSK_PICK(128, 1, 1, true) : CSK_PICK(64, 1, 1, true);
+    else if (big) E == 2 ? (head_step == 2 ? CSK_PICK(128, 2, 2, false) : CSK_PICK(128, 2, 1, false)) : CSK_PICK(128, 1, 1, false);
+    else E == 4 ? CSK_PICK(64, 4, 1, false) : E == 2 ? CSK_PICK(64, 2, 1, false) : CSK_PICK(64, 1, 1, false);
+#undef CSK_PICK
+    const size_t lds = (size_t)(9 * KC * MT + stage_floats) * sizeof(float);
+    dim3 grid((unsigned)((P + NP - 1) / NP), p.Mpad / MT, (n_emit / E) * p.ksplit);
     hipStream_t s = (hipStream_t)stream;
-    void (*kern)(StepParams) = p.ksplit > 1 ? (big ? tcn_step_kernel<128, true> : tcn_step_kernel<64, true>)
-                                            : (big ? tcn_step_kernel<128, false> : tcn_step_kernel<64, false>);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, p);
     if (p.ksplit > 1) {
@@ -403,7 +446,7 @@ __global__ __launch_bounds__(256) void fuse_rank_kernel(const FuseParams p, cons
         tv = p.preds[0][n * p.sample_stride + tgt * p.class_stride];
         for (int s = 1; s < p.n_streams; ++s) {
             const float v = p.preds[s][n * p.sample_stride + tgt * p.class_stride];
-            tv = p.use_max ? fmaxf(tv, v) : tv + v;
+            tv = p.use_max ? __builtin_elementwise_maximum(tv, v) : tv + v;   // NaN-propagating, as np.maximum
         }
     }
     int higher = 0;
@@ -411,7 +454,7 @@ __global__ __launch_bounds__(256) void fuse_rank_kernel(const FuseParams p, cons
         float f = p.preds[0][n * p.sample_stride + c * p.class_stride];
         for (int s = 1; s < p.n_streams; ++s) {
             const float v = p.preds[s][n * p.sample_stride + c * p.class_stride];
-            f = p.use_max ? fmaxf(f, v) : f + v;
+            f = p.use_max ? __builtin_elementwise_maximum(f, v) : f + v;
         }
         if (fused) fused[n * p.classes + c] = f;
         higher += (f > tv) ? 1 : 0;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             for (int g = 0; g < 16; ++g) {
                 float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
                 float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
-                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                if (p.relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
                 acc[mi][0][g] = __uint_as_float(sw[0]);        // row rbase + mi*32 + (g&3) + 8(g>>2), this lane's column qb
                 acc[mi][1][g] = __uint_as_float(sw[1]);        // row + 4

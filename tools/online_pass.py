@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Workload of the online-path profile passes (tools/profile_online.sh): EXACTLY bench.py's online shape --
+CoST-GCN, 1024 streams, cycles of 4 frames, native plan -- from a clean state, warm-up cycles included (the trace
+summariser tools/summarize_layers.py keeps the last --cycles cycles of every HIP stream, which are steady state:
+all ten blocks emit, the temporal pool is full).
+usage: python tools/online_pass.py [--shards 1|2] [--fpl 4] [--cycles 24] [--streams 1024]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import _bootstrap  # noqa: E402
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shards", type=int, default=1)
+ap.add_argument("--fpl", type=int, default=4)
+ap.add_argument("--cycles", type=int, default=24)
+ap.add_argument("--streams", type=int, default=1024)
+ap.add_argument("--warm-cycles", type=int, default=0, help="default: enough to fill the stack and the temporal pool")
+args = ap.parse_args()
+
+pkg = _bootstrap.load()
+from continual_skeletons_amd import parallel  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def make():
+    net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+    bench.randomise_(net, seed=0)
+    return net.to(dev)
+
+
+eng = parallel.StreamShards(make, args.streams, args.shards, dev)
+frames = torch.rand((8, args.streams, 3, 25, 2), device=dev, generator=torch.Generator(device=dev).manual_seed(200))
+warm = args.warm_cycles or (76 + 4 * 56 + args.fpl - 1) // args.fpl + 2
+fi = 0
+
+
+def cycle():
+    global fi
+    out = eng.forward_cycle([frames[(fi + f) % 8] for f in range(args.fpl)])
+    fi += args.fpl
+    return out
+
+
+for _ in range(warm):
+    cycle()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.cycles):
+    out = cycle()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+assert out is not None and bool(torch.isfinite(out).all())
+print(f"ONLINE_PASS shards={args.shards} fpl={args.fpl} streams={args.streams} warm_cycles={warm} cycles={args.cycles} "
+      f"ms_per_cycle={dt / args.cycles * 1e3:.4f} frames_per_s={args.fpl * args.streams * args.cycles / dt:.0f}")
