@@ -498,6 +498,262 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const Gcn
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sparse-graph GCN stage, second form (the default): PING-PONG LDS, TRICKLED staging loads, THREE workgroups per CU.
+// Same arithmetic and summation order as gcn_stage_sparse_kernel (bitwise-equal results); what changes is the chunk
+// pipeline and the occupancy.  The first form spends per 16-channel chunk ~1.8-2.6 k of ~15-16 k cycles in [barrier,
+// commit, barrier] with the MFMA pipe idle on both co-resident workgroups (they run in lockstep), and issues the next
+// chunk's 18-23 global loads in one burst in front of the MFMAs (in-order waves: VMEM-issue stalls delay the first
+// MFMAs; measured 14.5 k cycles per MFMA segment at C = 256 against 12.3 k of MFMA work).  Here
+//   * LDS holds two chunk buffers: chunk c+1 is committed (registers -> LDS[other]) at the START of iteration c, in
+//     front of chunk c's MFMAs, so one barrier per chunk suffices (everybody done reading LDS[cur] and writing
+//     LDS[other]);
+//   * the loads of chunk c+2 are issued a few at a time between the first MFMA k-steps of chunk c (register prefetch
+//     one chunk ahead of the commit, as before), pinned there with sched_barrier;
+//   * the epilogue operands (32 biases + 64 residual values per lane) are loaded after the K loop, one 32-row half at
+//     a time, instead of being prefetched under the last chunk: with 8-channel chunks the kernel then fits 168
+//     registers and <= 45 KB of LDS, i.e. THREE workgroups per CU.  A third wave per SIMD is what pays here (-7..-13 %
+//     against the first form, in-process A/B tools/ab_gcn_probe.py; the same pipeline at two per CU: -1..-12 %): unlike
+//     the TCN loop, a GCN k-step carries 18 LDS reads + 14 VALU per 12 MFMAs whose latency another wave has to cover.
+// KCG_ = channels per chunk.
+// ------------------------------------------------------------------------------------------------
+template <int MT, bool CONVRES, int KCG_>
+__global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const GcnParams p) {
+    constexpr int NT = 16384 / MT;
+    constexpr int WM = MT / 64;
+    constexpr int R = CONVRES ? 4 : 3;
+    constexpr int M4 = MT / 4;
+    constexpr int WB = (R * KCG_ * M4 + NTHREADS - 1) / NTHREADS;   // f32x4 of weights per thread per chunk
+    constexpr int RPW = KCG_ / (NTHREADS / 64);            // activation rows per wave per chunk
+    constexpr int NJ = MT == 128 ? 3 : 5;                  // 64-lane sweeps per activation row (span <= 192 / 320)
+    constexpr int NL = WB + RPW * NJ;                      // staging loads per thread per chunk
+    constexpr int NS = KCG_ / 2;                           // MFMA k-steps per chunk
+    constexpr int NH = NS / 2;                             // ... of which the first NH carry the next-next chunk's loads
+    static_assert(KCG_ % 8 == 0, "a chunk is a whole number of rows per wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int V = p.V;
+    const int wsz = R * KCG_ * MT, bsz = KCG_ * p.ldb, bufsz = wsz + bsz;     // one chunk buffer: Wl [R][KCG][MT], Bx [KCG][ldb]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
+    const int seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int Q = p.frames * V;
+    const int qend = min(q0 + NT, Q);
+    const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
+    const int span = (tb - ta + 1) * V;
+    // per-lane adjacency entries of the two output columns this lane feeds (B operand: column = lane & 31)
+    int eoff[2][6];
+    float eval[2][6];
+    int ioff[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+        const int t = div_magic(q, p.vmagic);
+        const int w = q - t * V, fb = (t - ta) * V;
+        ioff[ni] = fb + w;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;          // subsets 0,1: one entry; subset 2: four
+            const bool have = k < p.ell_cnt[r];
+            const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
+            eoff[ni][e] = fb + (have ? p.ell_src[idx] : 0);
+            eval[ni][e] = have ? p.ell_val[idx] : 0.f;
+        }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
+    const float *wbase = p.w + m0;
+    // staging registers + chunk-invariant offsets
+    f32x4 wv[WB];
+    unsigned wgo[WB], wlo[WB];
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+        const int e = min(u * NTHREADS + tid, R * KCG_ * M4 - 1);   // surplus threads re-stage the last vector
+        const int row = e / M4, m4 = e % M4;
+        wgo[u] = (unsigned)(((row / KCG_) * p.CinPad + (row % KCG_)) * p.Mpad + m4 * 4);
+        wlo[u] = (unsigned)(e * 4);
+    }
+    float bv[RPW][NJ];
+    unsigned bgo[NJ], blo[NJ];
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+        const int j = min(u * 64 + lane, span - 1);
+        bgo[u] = (unsigned)(ta * V + j);                   // always inside [0, Q): whole frames of this segment
+        blo[u] = (unsigned)j;
+    }
+    // staging load i of chunk c0 (i is a literal after unrolling): 0..WB-1 weights, then activation (row, sweep) pairs
+    auto issue_one = [&](int i, int c0) {
+        if (i < WB) {
+            wv[i] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)c0 * p.Mpad + wgo[i]);
+        } else {
+            const int rr = (i - WB) / NJ, u = (i - WB) % NJ;
+            // channels >= Cin: the row is CLAMPED, not zeroed -- the packed weights of padding channels are zero, so a
+            // finite duplicate contributes nothing (and a NaN / Inf duplicate only reaches outputs the real row already
+            // poisons); a select here would make the compiler wait for the load right behind its issue
+            const int c = min(c0 + wave + rr * (NTHREADS / 64), p.Cin - 1);
+            bv[rr][u] = (seg_base + (int64_t)c * p.x_chan_stride)[bgo[u]];
+        }
+    };
+    auto commit = [&](float *buf) {
+        float *Wl = buf, *Bx = buf + wsz;
+#pragma unroll
+        for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(Wl + wlo[u]) = wv[u];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            float *dst = Bx + (wave + rr * (NTHREADS / 64)) * p.ldb;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) dst[blo[u]] = bv[rr][u];
+        }
+    };
+    const int offA = wm * 64 + l31;
+    // one MFMA k-step pair of the chunk in `buf`: the aggregated B operand is formed on the fly (see the first form)
+    auto mfma_step = [&](const float *buf, int s) {
+        const float *Wl = buf, *Bx = buf + wsz;
+        const int kk = 2 * s + kh;
+        const float *bx = Bx + kk * p.ldb;
+        float b[R][2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float x0 = bx[eoff[ni][0]];
+            b[0][ni] = eval[ni][0] * x0;
+            b[1][ni] = eval[ni][1] * bx[eoff[ni][1]];
+            float s2 = eval[ni][2] * bx[eoff[ni][2]];
+            s2 = fmaf(eval[ni][3], bx[eoff[ni][3]], s2);
+            s2 = fmaf(eval[ni][4], bx[eoff[ni][4]], s2);
+            s2 = fmaf(eval[ni][5], bx[eoff[ni][5]], s2);
+            b[2][ni] = s2;
+            if (CONVRES) b[R - 1][ni] = bx[ioff[ni]];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float *wr = Wl + (r * KCG_ + kk) * MT + offA;
+            const float a0 = wr[0], a1 = wr[32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][1], acc[1][1], 0, 0, 0);
+        }
+    };
+
+    const int nchunks = p.CinPad / KCG_;                   // CinPad is a multiple of CSK_CPAD = 16
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_one(i, 0);
+    commit(smem);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) issue_one(i, KCG_);
+    }
+    __syncthreads();
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        float *cur = smem + (c & 1) * bufsz, *oth = smem + ((c & 1) ^ 1) * bufsz;
+        commit(oth);                                       // chunk c+1: registers -> the other buffer
+        // chunk c+2's loads; past the end the last chunk is re-loaded into the (then dead) staging registers, so that
+        // the k-step sequence below stays ONE basic block (a uniform branch per load group would confine the
+        // scheduler's LDS-read / MFMA interleave to single k-steps)
+        const int cnext = min(c + 2, nchunks - 1) * KCG_;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // all loads go out in the FIRST half of the k-steps: the second half (and the barrier) is their latency
+            // cover before the commit at the top of the next iteration
+            if (s < NH) {
+#pragma unroll
+                for (int i = s * NL / NH; i < (s + 1) * NL / NH; ++i) issue_one(i, cnext);
+                // pin the loads to this k-step: left alone, the machine scheduler sinks all of them to the end of the
+                // block, right in front of the barrier and the commit that needs them (a mask that only holds back
+                // vector-memory instructions does not help: the MFMAs are then hoisted over the loads instead)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_step(cur, s);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+    const float *last = smem + ((nchunks - 1) & 1) * bufsz;
+    // Epilogue operands: loaded after the K loop, one 32-row half at a time (register budget of three workgroups / CU)
+    const int rbase = m0 + wm * 64;
+    const bool full = p.fast_epi && m0 + MT <= p.Cout;
+    const unsigned kh4 = 4u * (unsigned)kh;
+    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+    const int qb = q0 + wn * 64 + lane;
+    const bool qv = qb < Q;
+    float bb[2][16], rv[2][2][16];
+    auto load_half = [&](int mi) {
+        if (full) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bb[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const unsigned lo = 4u * (kh4 * (unsigned)p.x_chan_stride + (unsigned)min(q0 + wn * 64 + ni * 32 + l31, Q - 1));
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float *rrow = seg_base + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.x_chan_stride;
+                    rv[ni][mi][g] = CONVRES ? 0.f : ld_lane(rrow, lo);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bb[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    rv[ni][mi][g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
+                }
+            }
+        }
+    };
+    // ReLU(acc + bias + identity residual); permlane32_swap pairs the ni = 0/1 registers so that every store
+    // instruction writes one 256-B contiguous row segment (see tcn_stage_kernel)
+    auto finish_half = [&](int mi) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float v0 = relu_nan(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g]);
+            const float v1 = relu_nan(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+            acc[mi][0][g] = __uint_as_float(sw[0]);       // row (g & 3) + 8*(g >> 2), column qb
+            acc[mi][1][g] = __uint_as_float(sw[1]);       // row + 4
+        }
+        if (full) {
+            if (qv) {
+                const unsigned qo = 4u * (unsigned)qb;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.y_chan_stride;
+                    st_lane(orow, qo, acc[mi][0][g]);
+                    st_lane(orow + 4 * p.y_chan_stride, qo, acc[mi][1][g]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
+                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = acc[mi][0][g];
+                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = acc[mi][1][g];
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mfma_step(last, s);
+    load_half(0);
+    finish_half(0);
+    load_half(1);
+    finish_half(1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
@@ -548,9 +804,17 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
                         !csk_diag_flag("CSK_GCN_GENERAL");
     if (sparse) {
         const int R = p.R;
-        const size_t lds2 = (size_t)(R * KCG * MT + KCG * p.ldb) * sizeof(float);
-        void (*k)(GcnParams) = big ? (R == 4 ? gcn_stage_sparse_kernel<128, true> : gcn_stage_sparse_kernel<128, false>)
-                                   : (R == 4 ? gcn_stage_sparse_kernel<64, true> : gcn_stage_sparse_kernel<64, false>);
+        size_t lds2;
+        void (*k)(GcnParams);
+        if (csk_diag_flag("CSK_GCN_V1") || p.stamps) {     // first form: two barriers per chunk, burst loads (A/B, stamps)
+            lds2 = (size_t)(R * KCG * MT + KCG * p.ldb) * sizeof(float);
+            k = big ? (R == 4 ? gcn_stage_sparse_kernel<128, true> : gcn_stage_sparse_kernel<128, false>)
+                    : (R == 4 ? gcn_stage_sparse_kernel<64, true> : gcn_stage_sparse_kernel<64, false>);
+        } else {                                           // ping-pong LDS, trickled loads, 3 workgroups / CU
+            lds2 = 2 * (size_t)(R * 8 * MT + 8 * p.ldb) * sizeof(float);
+            k = big ? (R == 4 ? gcn_stage_sparse2_kernel<128, true, 8> : gcn_stage_sparse2_kernel<128, false, 8>)
+                    : (R == 4 ? gcn_stage_sparse2_kernel<64, true, 8> : gcn_stage_sparse2_kernel<64, false, 8>);
+        }
         const int e = csk_ensure_lds((const void *)k, lds2);
         if (e) return e;
         hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds2, (hipStream_t)stream, p);
