@@ -34,6 +34,8 @@ struct TcnParams {
 
 template <int MT, int NJ>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams p) {
+    constexpr int OCC = 2;   // 3 (epilogue operands loaded after the K loop, <= 168 registers) was measured: the K loop's
+                             // staging registers then spill and the stage runs 13-19 % slower
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,43 +89,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     const int rbase = m0 + wm * 64;
     const bool full = p.fast_epi && m0 + MT <= p.Cout;
     const unsigned kh4 = 4u * (unsigned)kh;
-    auto issue_epilogue_loads = [&]() {
+    auto load_half = [&](int mi) {
         if (full) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) bv[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+            for (int g = 0; g < 16; ++g) bv[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
                 const int t = div_magic(qc, p.vmagic);
                 const unsigned qres = ident ? 4u * (kh4 * (unsigned)rcs + (unsigned)((t * p.stride + p.res_off) * V + (qc - t * V))) : 0u;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const float *rrow = rseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * rcs;
-                        rv[ni][mi][g] = ident ? ld_lane(rrow, qres) : 0.f;
-                    }
+                for (int g = 0; g < 16; ++g) {
+                    const float *rrow = rseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * rcs;
+                    rv[ni][mi][g] = ident ? ld_lane(rrow, qres) : 0.f;
+                }
             }
-            return;
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        } else {
 #pragma unroll
             for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
-            const int t = div_magic(qc, p.vmagic);
-            const int qres = ident ? (t * p.stride + p.res_off) * V + (qc - t * V) : 0;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 2; ++ni) {
+                const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
+                const int t = div_magic(qc, p.vmagic);
+                const int qres = ident ? (t * p.stride + p.res_off) * V + (qc - t * V) : 0;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
                     rv[ni][mi][g] = ident ? rseg[(int64_t)min(co, p.Cout - 1) * rcs + qres] : 0.f;
                 }
+            }
         }
     };
     const bool conv_res = p.res_mode == CSK_RES_CONV;
@@ -179,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         ws.commit(Wl);
         bs.commit(Bl, p.ldb, wave);
         __syncthreads();
-        if (!conv_res) issue_epilogue_loads();
+        if (!conv_res && OCC == 2) { load_half(0); load_half(1); }
         mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
     }
     // ---- phase 2: 1x1 strided residual conv over the block input (models/base.py:372-374)
@@ -207,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         ws.commit(Wl);
         bs.commit(Bl, p.ldb, wave);
         __syncthreads();
-        issue_epilogue_loads();
+        if (OCC == 2) { load_half(0); load_half(1); }
         mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
     }
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
@@ -216,42 +210,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     // writes two 128-B half rows (rows r and r+4).  v_permlane32_swap of the ni=0 / ni=1 registers gives each
     // lane half the SAME row instead: lanes 0-31 columns 0-31, lanes 32-63 columns 32-63 of row r (first
     // result) and of row r+4 (second) -> every store instruction writes one 256-B contiguous row segment.
-    {
-        const int qb = q0 + wn * 64 + lane;                    // column of this lane after the swap
-        const bool qv = qb < qend;
+    const int qb = q0 + wn * 64 + lane;                    // column of this lane after the swap
+    const bool qv = qb < qend;
+    auto finish_half = [&](int mi) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
-                float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
-                if (p.relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
-                acc[mi][0][g] = __uint_as_float(sw[0]);        // row rbase + mi*32 + (g&3) + 8(g>>2), this lane's column qb
-                acc[mi][1][g] = __uint_as_float(sw[1]);        // row + 4
-            }
+        for (int g = 0; g < 16; ++g) {
+            float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
+            float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
+            if (p.relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+            acc[mi][0][g] = __uint_as_float(sw[0]);        // row rbase + mi*32 + (g&3) + 8(g>>2), this lane's column qb
+            acc[mi][1][g] = __uint_as_float(sw[1]);        // row + 4
+        }
         if (full) {
             if (qv) {
                 const unsigned qo = 4u * (unsigned)qb;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * Q;
-                        st_lane(orow, qo, acc[mi][0][g]);
-                        st_lane(orow + 4 * (int64_t)Q, qo, acc[mi][1][g]);
-                    }
+                for (int g = 0; g < 16; ++g) {
+                    float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * Q;
+                    st_lane(orow, qo, acc[mi][0][g]);
+                    st_lane(orow + 4 * (int64_t)Q, qo, acc[mi][1][g]);
+                }
             }
         } else {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
-                    if (qv && row0 < p.Cout) oseg[(int64_t)row0 * Q + qb] = acc[mi][0][g];
-                    if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * Q + qb] = acc[mi][1][g];
-                }
+            for (int g = 0; g < 16; ++g) {
+                const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
+                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * Q + qb] = acc[mi][0][g];
+                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * Q + qb] = acc[mi][1][g];
+            }
         }
+    };
+    if (OCC == 2) {
+        finish_half(0);
+        finish_half(1);
+    } else {
+        load_half(0);
+        finish_half(0);
+        load_half(1);
+        finish_half(1);
     }
     if (p.stamps && tid == 0) {
         unsigned long long st3 = __builtin_amdgcn_s_memtime();
