@@ -14,7 +14,7 @@ def closed_form_input(shape, salt=0.0):
     return (v - np.floor(v)).astype(np.float32).reshape(shape)
 
 
-def closed_form_state_dict(shapes, salt0=1000.0):
+def closed_form_state_dict(shapes, salt0=1000.0, gcn_bn_scale=1.0):
     """Deterministic ST-GCN-style state_dict from {key: shape} (iterated in sorted key order).
 
     * BatchNorm (keys ending .weight/.bias/.running_mean/.running_var next to a running_mean):
@@ -22,6 +22,8 @@ def closed_form_state_dict(shapes, salt0=1000.0):
       bias/mean U(-.5,.5), var U(.5,1.5); num_batches_tracked = 0.
     * graph_attn U(.5,1.5); ``A`` is NOT generated (caller keeps the graph's adjacency).
     * conv / linear weight: U(-1,1) * sqrt(3 / fan_in) * 0.9 ; bias U(-.2,.2).
+    * ``gcn_bn_scale`` multiplies the ``gcn.bn`` weights (A-GCN fixture G8: the adaptive adjacency sums ~V joints with
+      weights ~1, so the graph conv's BN must scale down for activations to stay O(1) through ten blocks).
     """
     keys = sorted(shapes)
     bn_prefixes = {k[: -len("running_mean")] for k in keys if k.endswith("running_mean")}
@@ -42,6 +44,8 @@ def closed_form_state_dict(shapes, salt0=1000.0):
                 v = 0.5 + u
                 if pre.endswith("tcn.bn."):
                     v = v * 0.35
+                if pre.endswith("gcn.bn."):
+                    v = v * gcn_bn_scale
             elif leaf == "running_var":
                 v = 0.5 + u
             else:

@@ -13,7 +13,11 @@ StGcn.__init__/forward (models/st_gcn/st_gcn.py:20-65) -- execute verbatim.
 BatchNorm affine/statistics and graph_attn are RANDOMISED: with the default init
 (gcn.bn.weight = 1e-6, models/base.py:256-257) the whole aggregation branch is invisible at 1e-4.
 
-usage: python tests/golden/make_golden.py
+Every fixture seeds the global RNG and its own generator, so the script regenerates the committed files
+bit-identically; ``--verify`` proves it (and, independently, reloads each stored state_dict into the reference class
+and re-runs it on the stored input: max |diff| must be 0.0).
+
+usage: python tests/golden/make_golden.py [--verify]
 """
 import os
 import sys
@@ -101,132 +105,221 @@ def sd_np(module):
     return {"sd/" + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
 
 
-def main():
-    _install_stubs()
+def _ref():
+    """The reference's own classes (imported once, under the name-only stubs)."""
+    if "models.base" not in sys.modules:
+        _install_stubs()
     from datasets import kinetics, ntu_rgbd
-    from models.a_gcn.a_gcn import AdaptiveGraphConvolution
+    from models.a_gcn.a_gcn import AdaptiveGraphConvolution, AGcn
     from models.base import GraphConvolution, SpatioTemporalBlock, TemporalConvolution
     from models.st_gcn.st_gcn import StGcn
+    return types.SimpleNamespace(A_ntu=ntu_rgbd.graph.A, A_kin=kinetics.graph.A, GraphConvolution=GraphConvolution,
+                                 TemporalConvolution=TemporalConvolution, SpatioTemporalBlock=SpatioTemporalBlock,
+                                 AdaptiveGraphConvolution=AdaptiveGraphConvolution, StGcn=StGcn, AGcn=AGcn)
 
+
+def _seeded(seed):
+    """Every fixture seeds BOTH the global RNG (the reference's kaiming / normal inits draw from it) and its own
+    generator (randomise(), inputs), so that a fixture regenerates bit-identically."""
+    torch.manual_seed(seed)
+    return torch.Generator().manual_seed(seed)
+
+
+G3_VARIANTS = {
+    # tag: (cin, cout, stride, residual, temporal_padding)
+    "nores": (4, 4, 1, False, 4),
+    "ident": (4, 4, 1, True, -1),
+    "convres": (2, 4, 1, True, -1),
+    "strided": (2, 4, 2, True, -1),
+    "nopad": (4, 4, 1, True, 0),
+    "nopad_strided": (2, 4, 2, True, 0),
+}
+G2_VARIANTS = {"k9s1p4": (9, 1, 4), "k9s2p4": (9, 2, 4), "k1s2p0": (1, 2, 0), "k9s1p0": (9, 1, 0)}
+G6_VARIANTS = {"ntu": (25, 60, 2, 106), "kin": (18, 400, 1, 107)}     # tag: (V, classes, n, seed)
+G8 = dict(V=18, classes=400, n=1, seed=109, gcn_bn_scale=0.06)
+
+
+def _whole_model(R, cls, A, V, classes, n, seed, gcn_bn_scale=1.0):
+    """StGcn / AGcn of the reference built without its Ride shell (cls.__new__ + nn.Module.__init__ + the attributes
+    the dataset mixin would provide), closed-form weights, closed-form input; -> (arrays to store, net, x)."""
+    torch.manual_seed(seed)
+    net = cls.__new__(cls)
+    nn.Module.__init__(net)
+    net.input_shape = (3, 300, V, 2)
+    net.num_classes = classes
+    net.graph = types.SimpleNamespace(A=A)
+    cls.__init__(net, {})
+    net.eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    gen = closed_form_state_dict(shapes, salt0=float(seed), gcn_bn_scale=gcn_bn_scale)
+    full = {k: (torch.from_numpy(gen[k]) if k in gen else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(full)
+    x = torch.from_numpy(closed_form_input((n, 3, 300, V, 2), salt=6.0 + seed))
+    taps = {}
+    hooks = [net.layers[f"layer{i}"].register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, out))
+             for i in (1, 5, 8, 10)]
+    with torch.no_grad():
+        logits = net(x)
+    for h in hooks:
+        h.remove()
+    extra = {}
+    for i, t in taps.items():
+        extra[f"layer{i}_sub"] = t.numpy().reshape(-1)[::997].copy()
+        extra[f"layer{i}_absmax"] = np.array(float(t.abs().max()))
+    nparams = sum(p.numel() for p in net.parameters())
+    return dict(logits=logits.numpy(), n=np.array(n), salt=np.array(6.0 + seed), seed=np.array(float(seed)),
+                nparams=np.array(nparams), gcn_bn_scale=np.array(gcn_bn_scale), sd_keys=np.array(list(shapes.keys())),
+                sd_shapes=np.array([str(list(v)) for v in shapes.values()]), **extra)
+
+
+def generate():
+    """name -> dict of arrays, produced by the reference's classes.  Deterministic (see _seeded)."""
+    R = _ref()
     torch.set_num_threads(4)
-    A_ntu, A_kin = ntu_rgbd.graph.A, kinetics.graph.A
-    save = lambda name, **kw: np.savez_compressed(os.path.join(OUT, name), **kw)  # noqa: E731
-
+    out = {}
     # G0 -- adjacency, exact
-    save("g0_graphs.npz", ntu=A_ntu, kinetics=A_kin)
-
+    out["g0_graphs"] = dict(ntu=R.A_ntu, kinetics=R.A_kin)
     # G1 -- GraphConvolution 4->4 (identity gcn_residual) and 3->8 (conv gcn_residual), (2,C,6,25)
-    g = torch.Generator().manual_seed(101)
-    for tag, (ci, co) in {"eq": (4, 4), "neq": (3, 8)}.items():
-        m = GraphConvolution(ci, co, A_ntu).eval()
+    for j, (tag, (ci, co)) in enumerate({"eq": (4, 4), "neq": (3, 8)}.items()):
+        g = _seeded(1010 + j)
+        m = R.GraphConvolution(ci, co, R.A_ntu).eval()
         randomise(m, g)
         x = torch.rand((2, ci, 6, 25), generator=g)
         with torch.no_grad():
             y = m(x)
-        save(f"g1_gcn_{tag}.npz", x=x.numpy(), y=y.numpy(), **sd_np(m))
-
+        out[f"g1_gcn_{tag}"] = dict(x=x.numpy(), y=y.numpy(), **sd_np(m))
     # G2 -- TemporalConvolution variants, (2,4,20,25) (mirrors tests/test_cost_gcn.py:37-68)
-    g = torch.Generator().manual_seed(102)
-    for tag, (k, s, p) in {"k9s1p4": (9, 1, 4), "k9s2p4": (9, 2, 4), "k1s2p0": (1, 2, 0), "k9s1p0": (9, 1, 0)}.items():
-        m = TemporalConvolution(4, 4, k, s, p).eval()
+    for j, (tag, (k, s, p)) in enumerate(G2_VARIANTS.items()):
+        g = _seeded(1020 + j)
+        m = R.TemporalConvolution(4, 4, k, s, p).eval()
         randomise(m, g)
         x = torch.rand((2, 4, 20, 25), generator=g)
         with torch.no_grad():
             y = m(x)
-        save(f"g2_tcn_{tag}.npz", x=x.numpy(), y=y.numpy(), meta=np.array([k, s, p]), **sd_np(m))
-
+        out[f"g2_tcn_{tag}"] = dict(x=x.numpy(), y=y.numpy(), meta=np.array([k, s, p]), **sd_np(m))
     # G3 -- SpatioTemporalBlock variants, T=20, B=2, V=25 (mirrors tests/test_cost_gcn.py:71-271,
     #       tests/test_st_gcn_mod.py:11-54); each also serves as the step oracle via the index map
-    g = torch.Generator().manual_seed(103)
-    variants = {
-        # tag: (cin, cout, stride, residual, temporal_padding)
-        "nores": (4, 4, 1, False, 4),
-        "ident": (4, 4, 1, True, -1),
-        "convres": (2, 4, 1, True, -1),
-        "strided": (2, 4, 2, True, -1),
-        "nopad": (4, 4, 1, True, 0),
-        "nopad_strided": (2, 4, 2, True, 0),
-    }
-    for tag, (ci, co, s, res, tp) in variants.items():
-        m = SpatioTemporalBlock(ci, co, A_ntu, s, res, temporal_padding=tp).eval()
+    for j, (tag, (ci, co, s, res, tp)) in enumerate(G3_VARIANTS.items()):
+        g = _seeded(1030 + j)
+        m = R.SpatioTemporalBlock(ci, co, R.A_ntu, s, res, temporal_padding=tp).eval()
         randomise(m, g)
         x = torch.rand((2, ci, 20, 25), generator=g)
         with torch.no_grad():
             y = m(x)
-        save(f"g3_block_{tag}.npz", x=x.numpy(), y=y.numpy(), meta=np.array([ci, co, s, int(res), tp]), **sd_np(m))
-
+        out[f"g3_block_{tag}"] = dict(x=x.numpy(), y=y.numpy(), meta=np.array([ci, co, s, int(res), tp]), **sd_np(m))
     # G4 -- 3-block stack 3->3 (no res) ->3 (identity) ->4 (stride 2), T=40 (tests/test_cost_gcn.py:274-326)
-    g = torch.Generator().manual_seed(104)
+    g = _seeded(104)
     stack = nn.Sequential(
-        SpatioTemporalBlock(3, 3, A_ntu, residual=False),
-        SpatioTemporalBlock(3, 3, A_ntu),
-        SpatioTemporalBlock(3, 4, A_ntu, stride=2),
+        R.SpatioTemporalBlock(3, 3, R.A_ntu, residual=False),
+        R.SpatioTemporalBlock(3, 3, R.A_ntu),
+        R.SpatioTemporalBlock(3, 4, R.A_ntu, stride=2),
     ).eval()
     randomise(stack, g)
     x = torch.rand((2, 3, 40, 25), generator=g)
     with torch.no_grad():
         y = stack(x)
-    save("g4_stack.npz", x=x.numpy(), y=y.numpy(), **sd_np(stack))
-
+    out["g4_stack"] = dict(x=x.numpy(), y=y.numpy(), **sd_np(stack))
     # G5 -- BASELINE config 1: SpatioTemporalBlock(3,64,A_ntu,residual=False) on (2,3,300,25)
-    g = torch.Generator().manual_seed(0)
-    m = SpatioTemporalBlock(3, 64, A_ntu, residual=False).eval()
+    g = _seeded(105)
+    m = R.SpatioTemporalBlock(3, 64, R.A_ntu, residual=False).eval()
     randomise(m, g)
     x = torch.from_numpy(closed_form_input((2, 3, 300, 25), salt=5.0))
     with torch.no_grad():
         y = m(x)
-    yf = y.numpy().reshape(-1)
-    save("g5_config1_block.npz", y_sub7=yf[::7].copy(), y_chan_sum=y.sum(dim=(0, 2, 3)).numpy(),
-         y_shape=np.array(y.shape), **sd_np(m))
-
-    # G6 -- full StGcn, NTU N=2 and Kinetics-shape N=1; closed-form input; logits in full,
+    out["g5_config1_block"] = dict(y_sub7=y.numpy().reshape(-1)[::7].copy(), y_chan_sum=y.sum(dim=(0, 2, 3)).numpy(),
+                                   y_shape=np.array(y.shape), **sd_np(m))
+    # G6 -- full StGcn, NTU N=2 and Kinetics-shape N=1; closed-form weights and input; logits in full,
     #       layers 1/5/8/10 subsampled
-    for tag, (A, V, classes, n, seed) in {"ntu": (A_ntu, 25, 60, 2, 106), "kin": (A_kin, 18, 400, 1, 107)}.items():
-        g = torch.Generator().manual_seed(seed)
-        torch.manual_seed(seed)
-        net = StGcn.__new__(StGcn)
-        nn.Module.__init__(net)
-        net.input_shape = (3, 300, V, 2)
-        net.num_classes = classes
-        net.graph = types.SimpleNamespace(A=A)
-        StGcn.__init__(net, {})
-        net.eval()
-        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-        gen = closed_form_state_dict(shapes, salt0=float(seed))
-        full = {k: (torch.from_numpy(gen[k]) if k in gen else v) for k, v in net.state_dict().items()}
-        net.load_state_dict(full)
-        x = torch.from_numpy(closed_form_input((n, 3, 300, V, 2), salt=6.0 + seed))
-        taps = {}
-        hooks = [net.layers[f"layer{i}"].register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, out))
-                 for i in (1, 5, 8, 10)]
-        with torch.no_grad():
-            logits = net(x)
-        for h in hooks:
-            h.remove()
-        extra = {}
-        for i, t in taps.items():
-            extra[f"layer{i}_sub"] = t.numpy().reshape(-1)[::997].copy()
-            extra[f"layer{i}_absmax"] = np.array(float(t.abs().max()))
-        nparams = sum(p.numel() for p in net.parameters())
-        save(f"g6_stgcn_{tag}.npz", logits=logits.numpy(), n=np.array(n), salt=np.array(6.0 + seed),
-             seed=np.array(float(seed)), nparams=np.array(nparams),
-             sd_keys=np.array(list(shapes.keys())), sd_shapes=np.array([str(list(v)) for v in shapes.values()]),
-             **extra)
-
+    for tag, (V, classes, n, seed) in G6_VARIANTS.items():
+        out[f"g6_stgcn_{tag}"] = _whole_model(R, R.StGcn, R.A_ntu if V == 25 else R.A_kin, V, classes, n, seed)
     # G7 -- AdaptiveGraphConvolution 3->8 and 8->8, V=18, T in {1,6} (T=1 is the CoAGCN step oracle)
-    g = torch.Generator().manual_seed(108)
-    for tag, (ci, co) in {"neq": (3, 8), "eq": (8, 8)}.items():
-        torch.manual_seed(108)
-        m = AdaptiveGraphConvolution(ci, co, A_kin).eval()
+    for j, (tag, (ci, co)) in enumerate({"neq": (3, 8), "eq": (8, 8)}.items()):
+        g = _seeded(1080 + j)
+        m = R.AdaptiveGraphConvolution(ci, co, R.A_kin).eval()
         randomise(m, g)
-        out = {}
+        o_ = {}
         for t in (1, 6):
             x = torch.rand((2, ci, t, 18), generator=g)
             with torch.no_grad():
-                out[f"x_t{t}"] = x.numpy()
-                out[f"y_t{t}"] = m(x).numpy()
-        save(f"g7_agcn_{tag}.npz", **out, **sd_np(m))
+                o_[f"x_t{t}"] = x.numpy()
+                o_[f"y_t{t}"] = m(x).numpy()
+        out[f"g7_agcn_{tag}"] = dict(**o_, **sd_np(m))
+    # G8 -- full AGcn (models/a_gcn/a_gcn.py:72-145), Kinetics shape, N=1: closed-form weights including non-trivial
+    #       a_conv / b_conv (the per-sample attention), logits + layer 1/5/8/10 taps
+    out["g8_agcn_kin"] = _whole_model(R, R.AGcn, R.A_kin, G8["V"], G8["classes"], G8["n"], G8["seed"], G8["gcn_bn_scale"])
+    return out
 
+
+def verify():
+    """Re-run the reference on every COMMITTED fixture: (a) regenerate all fixtures and demand bit-identical arrays;
+    (b) independently, reload each stored state_dict into the reference class, feed the stored input and demand
+    max |diff| == 0.0 against the stored output.  Exit status 1 on any difference."""
+    R = _ref()
+    torch.set_num_threads(4)
+    bad = []
+
+    def load(name):
+        d = np.load(os.path.join(OUT, name + ".npz"))
+        return {k: d[k] for k in d.files}, {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd/")}
+
+    def check(name, got, want):
+        diff = float(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64)).max())
+        print(f"  {name:28s} max |reference(stored sd, stored x) - stored y| = {diff}")
+        if diff != 0.0:
+            bad.append(name)
+
+    with torch.no_grad():
+        for tag, (ci, co) in {"eq": (4, 4), "neq": (3, 8)}.items():
+            a, sd = load(f"g1_gcn_{tag}")
+            m = R.GraphConvolution(ci, co, R.A_ntu).eval()
+            m.load_state_dict(sd, strict=True)
+            check(f"g1_gcn_{tag}", m(torch.from_numpy(a["x"])).numpy(), a["y"])
+        for tag, (k, s, p) in G2_VARIANTS.items():
+            a, sd = load(f"g2_tcn_{tag}")
+            m = R.TemporalConvolution(4, 4, k, s, p).eval()
+            m.load_state_dict(sd, strict=True)
+            check(f"g2_tcn_{tag}", m(torch.from_numpy(a["x"])).numpy(), a["y"])
+        for tag, (ci, co, s, res, tp) in G3_VARIANTS.items():
+            a, sd = load(f"g3_block_{tag}")
+            m = R.SpatioTemporalBlock(ci, co, R.A_ntu, s, res, temporal_padding=tp).eval()
+            m.load_state_dict(sd, strict=True)
+            check(f"g3_block_{tag}", m(torch.from_numpy(a["x"])).numpy(), a["y"])
+        a, sd = load("g4_stack")
+        stack = nn.Sequential(R.SpatioTemporalBlock(3, 3, R.A_ntu, residual=False), R.SpatioTemporalBlock(3, 3, R.A_ntu),
+                              R.SpatioTemporalBlock(3, 4, R.A_ntu, stride=2)).eval()
+        stack.load_state_dict(sd, strict=True)
+        check("g4_stack", stack(torch.from_numpy(a["x"])).numpy(), a["y"])
+        a, sd = load("g5_config1_block")
+        m = R.SpatioTemporalBlock(3, 64, R.A_ntu, residual=False).eval()
+        m.load_state_dict(sd, strict=True)
+        y = m(torch.from_numpy(closed_form_input((2, 3, 300, 25), salt=5.0)))
+        check("g5_config1_block", y.numpy().reshape(-1)[::7], a["y_sub7"])
+        for tag, (ci, co) in {"neq": (3, 8), "eq": (8, 8)}.items():
+            a, sd = load(f"g7_agcn_{tag}")
+            m = R.AdaptiveGraphConvolution(ci, co, R.A_kin).eval()
+            m.load_state_dict(sd, strict=True)
+            for t in (1, 6):
+                check(f"g7_agcn_{tag} T={t}", m(torch.from_numpy(a[f"x_t{t}"])).numpy(), a[f"y_t{t}"])
+    # (a) everything, including G0 / G6 / G8 (whose weights are closed-form, not stored): regenerate and compare
+    fresh = generate()
+    for name, arrays in fresh.items():
+        d = np.load(os.path.join(OUT, name + ".npz"))
+        same = set(d.files) == set(arrays) and all(
+            np.array_equal(np.asarray(arrays[k]), d[k]) for k in d.files)
+        print(f"  {name:28s} regenerates bit-identically: {same}")
+        if not same:
+            bad.append(name + " (regeneration)")
+    if bad:
+        print("MISMATCH:", bad)
+        raise SystemExit(1)
+    print("all committed fixtures verified against the reference: 0.0")
+
+
+def main():
+    if "--verify" in sys.argv[1:]:
+        return verify()
+    for name, arrays in generate().items():
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"wrote fixtures to {OUT}: {tot / 1e6:.2f} MB")
 

@@ -6,7 +6,7 @@ import torch
 
 import _bootstrap
 from oracle import stgcn_oracle as o
-from tests.helpers import load_golden, max_err
+from tests.helpers import g8_state_dict, load_golden, max_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -105,3 +105,21 @@ def test_coagcn_model_steps_vs_oracle():
     for t in range(0, x.shape[2], 4):
         cyc += net.forward_cycle([xd[:, :, t + f].contiguous() for f in range(4)])
     assert len(cyc) == got.shape[2] and all(torch.equal(c.cpu(), got[:, :, i]) for i, c in enumerate(cyc))
+
+
+def test_full_agcn_golden():
+    """Fixture G8: the reference's whole AGcn model (Kinetics shape, closed-form weights with non-trivial a_conv /
+    b_conv) -- logits and the layer 1 / 5 / 8 / 10 activations of the HIP path against the reference's outputs."""
+    a, sd, x = g8_state_dict()
+    net = pkg.AGcn(A_KIN, (3, 300, 18, 2), 400).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    taps = {}
+    hooks = [net.layers[f"layer{i}"].register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, out))
+             for i in (1, 5, 8, 10)]
+    logits = net(x.to(DEV))
+    for h in hooks:
+        h.remove()
+    assert max_err(logits.cpu(), a["logits"]) <= TOL
+    for i in (1, 5, 8, 10):
+        assert max_err(taps[i].cpu().reshape(-1)[::997], a[f"layer{i}_sub"]) <= TOL

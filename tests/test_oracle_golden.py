@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import stgcn_oracle as o
-from tests.helpers import g6_state_dict, load_golden, max_err
+from tests.helpers import g6_state_dict, g8_state_dict, load_golden, max_err
 
 TOL = 1e-5  # same op sequence, same library -> differences are last-bit only
 
@@ -88,6 +88,18 @@ def test_g7_adaptive_graph_conv(tag, t):
     with torch.no_grad():
         y = o.adaptive_graph_conv(torch.from_numpy(a[f"x_t{t}"]), sd)
     assert max_err(y, a[f"y_t{t}"]) <= TOL
+
+
+def test_g8_full_agcn():
+    """Whole-model A-GCN (config 4) pinned on the reference's AGcn: logits and layer 1/5/8/10 taps."""
+    a, sd, x = g8_state_dict()
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == int(a["nparams"])
+    taps = {}
+    with torch.no_grad():
+        logits = o.stgcn_forward(x, sd, gcn=o.adaptive_graph_conv, taps=taps)
+    assert max_err(logits, a["logits"]) <= 1e-4
+    for i in (1, 5, 8, 10):
+        assert max_err(taps[f"layer{i}"].reshape(-1)[::997], a[f"layer{i}_sub"]) <= 1e-4
 
 
 # ---- continual protocol: the identities asserted by the reference's tests, against pinned clip outputs
