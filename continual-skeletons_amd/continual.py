@@ -433,7 +433,9 @@ class CoStGcn(_Folded):
 
     # ---- native executor ---------------------------------------------------------------------------
     def _weights_version(self):
-        return tuple(t._version for t in self._all_tensors)
+        """Identity + version of every parameter / buffer AS THEY ARE NOW (not as captured at bind time): an in-place
+        edit bumps _version, load_state_dict(assign=True) or swapping a sub-module changes id / data_ptr."""
+        return tuple((id(t), t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def _layer_structs(self, device):
         """(ctypes array of csk_co_layer, objects to keep alive) from the blocks' packed operands and state."""
@@ -464,7 +466,6 @@ class CoStGcn(_Folded):
         """csk_co_plan (include/cskel.h): one C call per cycle instead of ~25 ctypes calls.  Built for stacks of
         plain GraphConvolution blocks; other graph convs (A-GCN) keep the Python engine below."""
         self._destroy_plan()
-        self._all_tensors = list(self.parameters()) + list(self.buffers())
         if not self.use_native_plan:
             return
         if not all(type(self.layers[f"layer{i + 1}"].gcn) is GraphConvolution for i in range(10)):
@@ -581,7 +582,7 @@ class CoStGcn(_Folded):
         slot, nf, nl = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         rc = native.lib().csk_co_plan_cycle(self._plan, ptrs, len(frames), native.ptr(logits), ctypes.byref(slot),
                                             ctypes.byref(nf), ctypes.byref(nl), native.stream_of(frames[0]))
-        native.check(rc, "csk_co_plan_cycle")
+        native.check(rc, "csk_co_plan_cycle")      # on failure the plan has put its counters back (executor.hip)
         self._frames += len(frames)
         self._feats += nf.value
         if nf.value == 0:
@@ -619,8 +620,11 @@ class CoStGcn(_Folded):
         lib = native.lib()
         head = self._feats % self.pool_size
         stream = native.stream_of(st10.out)
-        native.check(lib.csk_co_spatial_pool_f32(native.ptr(st10.out[slot]), native.ptr(self._pool_ring[head]), n, 256,
-                                                 m * v, self._p, stream), "csk_co_spatial_pool_f32")
+        if slot is None:                           # end padding of the pooling window: a zero feature
+            self._pool_ring[head].zero_()
+        else:
+            native.check(lib.csk_co_spatial_pool_f32(native.ptr(st10.out[slot]), native.ptr(self._pool_ring[head]), n, 256,
+                                                     m * v, self._p, stream), "csk_co_spatial_pool_f32")
         self._feats += 1
         if self._feats < self.pool_size - self.pool_padding:
             return None
@@ -660,14 +664,15 @@ class CoStGcn(_Folded):
         return self._cycle(frames)[2]
 
     def forward_steps(self, x, pad_end=False, update_state=True):
-        """(N, C, T, V, M) -> (N, classes, n_predictions) (empty last dim if nothing was emitted)."""
-        if pad_end:
-            raise NotImplementedError("model-level pad_end is not used by the reference (base.py:177)")
+        """(N, C, T, V, M) -> (N, classes, n_predictions) (empty last dim if nothing was emitted).  ``pad_end`` is handed
+        through to every module as in the reference (base.py:187-190): each block's temporal conv is flushed with its
+        ``padding`` zero frames, first block first, so that the stack emits what the clip stack computes for the same
+        frames, and the temporal average pool is flushed with ``pool_padding`` zero features."""
         if not update_state:                       # several frames overwrite live window slots: keep a copy of the slab
             self._ensure_bound(x[:, :, 0].contiguous())
             snap, keep = self._counters(), [t.clone() for t in self._state_tensors()]
             try:
-                return self.forward_steps(x, False, True)
+                return self.forward_steps(x, pad_end, True)
             finally:
                 for t, k in zip(self._state_tensors(), keep):
                     t.copy_(k)
@@ -677,9 +682,54 @@ class CoStGcn(_Folded):
             o = self.forward_step(x[:, :, t].contiguous())
             if o is not None:
                 outs.append(o)
+        if pad_end and x.shape[2] > 0:
+            outs += self._flush()
         if not outs:
             return torch.empty((x.shape[0], self.num_classes, 0), device=x.device)
         return torch.stack(outs, dim=2)
+
+    def _flush(self):
+        """End padding of the whole model (``pad_end=True``): returns the predictions it releases.  Runs on the Python
+        engine; a native plan's counters are read before and written back afterwards."""
+        plan = self.__dict__.get("_plan")
+        if plan:
+            buf = (ctypes.c_int64 * 22)()
+            native.check(native.lib().csk_co_plan_counters(plan, buf, 22, 0), "csk_co_plan_counters")
+            self._frames, self._feats = int(buf[0]), int(buf[1])
+            for i in range(10):
+                st = self.layers[f"layer{i + 1}"]._state
+                st.s, st.e = int(buf[2 + 2 * i]), int(buf[3 + 2 * i])
+        n = self._n
+        _, _, v, m = self.input_shape
+        outs = []
+        for i in range(10):
+            blk = self.layers[f"layer{i + 1}"]
+            res = blk.engine_advance(blk.padding, n * m, v, flush=True) if blk.padding else None
+            for j in range(i + 1, 10):             # what block i released travels down the rest of the stack
+                if res is None:
+                    break
+                res = self.layers[f"layer{j + 1}"].engine_advance(res[1], n * m, v)
+            if res is not None:
+                for jj in range(res[1]):
+                    o = self._head_step((res[0] + jj) % HIST, n)
+                    if o is not None:
+                        outs.append(o)
+        for _ in range(self.pool_padding):         # co.AvgPool1d end padding: zero features enter the window
+            o = self._head_step(None, n)
+            if o is not None:
+                outs.append(o)
+        if plan:
+            self._set_counters(self._counters_py())
+        return outs
+
+    def _counters_py(self):
+        snap = dict(frames=self._frames, feats=self._feats,
+                    layers=[(b._state.s, b._state.e) for b in (self.layers[f"layer{i + 1}"] for i in range(10))])
+        flat = [self._frames, self._feats]
+        for s_, e_ in snap["layers"]:
+            flat += [s_, e_]
+        snap["plan"] = flat
+        return snap
 
     def forward(self, x, forward_mode="clip"):
         """CoModelBase.forward (base.py:166-181).  'clip': whole-clip computation with the continual head

@@ -198,6 +198,14 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
     if (r < 1 || r > CSK_CO_MAX_CYCLE) CSK_FAIL("co_plan_cycle: r must be in [1, %d]", CSK_CO_MAX_CYCLE);
     *n_feat = *n_logits = 0;
     *last_slot = 0;
+    // A launch can fail half way through a cycle (bad pointer, capture / instantiate error): the counters are then put
+    // back to their values on entry, so that plan, caller-side counters and the frames == cnt[0].s invariant of the
+    // graph key stay consistent.  (Ring slots already overwritten belong to frames older than every window or to the
+    // cycle that failed; re-running the cycle rewrites them.)
+    struct Rollback {
+        csk_co_plan *p; long frames, feats; std::vector<BlockCounters> cnt; bool armed = true;
+        ~Rollback() { if (armed) { p->frames = frames; p->feats = feats; p->cnt = cnt; } }
+    } rollback{p, p->frames, p->feats, p->cnt};
     for (int f = 0; f < r; ++f) {                  // reshape1 + data_bn + reshape2 into the channel-major ring
         if (!frames[f]) CSK_FAIL("co_plan_cycle: null frame");
         float *dst = p->xin0 + (p->frames % CSK_CO_HIST) * (int64_t)p->C * p->P;
@@ -239,7 +247,7 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
         if (e == hipSuccess) e = hipStreamWaitEvent(cs, p->ev_out, 0);
         if (e != hipSuccess) return (int)e;
     }
-    if (rr == 0) return 0;
+    if (rr == 0) { rollback.armed = false; return 0; }
     *last_slot = slot0;
     *n_feat = rr;
     const csk_co_layer &last = p->layers.back();
@@ -260,5 +268,6 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
         if (rc) return rc;
         (*n_logits)++;
     }
+    rollback.armed = false;
     return 0;
 }

@@ -2,13 +2,16 @@
 //
 // State lives in a persistent HBM slab in CHANNEL-MAJOR layout: one frame of activations for all streams is
 // a (C, P) matrix, P = n_streams * M * V positions (padded to a multiple of 4), position = (skeleton, joint)
-// with the joint innermost.  Per block:
-//     y ring   [9][C_out][P]   post-GCN frames  (the (k-1)-frame window of co.Conv2d + the new frame)
-//     out ring [5][C_out][P]   block outputs    (doubles as the next block's residual FIFO, co.Delay(4))
-// A step of a block = gcn_stage on the new frame (gcn.hip, frames == skeletons) writing ring slot s % 9,
-// then -- on emitting steps -- tcn_step below: the 9 taps of the temporal conv are the 9 ring slots at the
-// SAME positions, so the GEMM is  D[co, p] = sum_r sum_c W[r][c][co] * ring[(head - 8 + r) % 9][c][p].
+// with the joint innermost.  Per block (depths: CSK_CO_YRING / CSK_CO_HIST = 16 / 16, include/cskel.h):
+//     y ring   [16][C_out][P]   post-GCN frames  (the (k-1) = 8-frame window of co.Conv2d + up to 8 new frames of a
+//                                launch cycle)
+//     out ring [16][C_out][P]   block outputs    (doubles as the next block's input / residual history, co.Delay(4),
+//                                plus the frames of a cycle in flight)
+// A cycle of a block = gcn_stage on the new frames (gcn.hip, frames == skeletons) writing ring slots s % 16 ..., then
+// tcn_step below for the emitting steps: the 9 taps of the temporal conv are 9 consecutive ring slots at the SAME
+// positions, so the GEMM is  D[co, p] = sum_r sum_c W[r][c][co] * ring[(head - 8 + r) % slots][c][p].
 // Zero-initialised slots reproduce the zero left-padding of the clip conv (models/base.py:307-334 semantics).
+// (A bare CoTemporalConvolution uses the same kernel on a ring of exactly k slots.)
 #include "mfma_core.h"
 
 // ------------------------------------------------------------------------------------------------

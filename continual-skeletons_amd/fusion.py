@@ -17,18 +17,27 @@ import torch
 from . import native
 
 
-def load_labels(label_path: str):
-    """``(names, labels)`` pickle of the NTU/Kinetics label files (multi_stream_eval.py:16-20)."""
-    with open(label_path, "rb") as f:
-        _, labels = pickle.load(f, encoding="latin1")
-    return labels
+def load_labels(label_path) -> np.ndarray:
+    """Targets of an NTU / Kinetics label file: a pickled ``(sample_names, labels)`` pair written by the reference's
+    dataset tooling under Python 2 (hence latin1), as read by multi_stream_eval.py:16-20 -> int64 array (N,)."""
+    blob = Path(label_path).read_bytes()
+    pair = pickle.loads(blob, encoding="latin1")
+    if not isinstance(pair, (tuple, list)) or len(pair) != 2:
+        raise ValueError(f"{label_path}: expected a pickled (sample_names, labels) pair")
+    return np.asarray(pair[1], dtype=np.int64)
 
 
-def load_preds(path: str) -> np.ndarray:
+def load_preds(path) -> np.ndarray:
+    """Stream predictions stored by the reference's test runs: a ``.npy`` array (N, classes[, steps])."""
     path = Path(path)
-    assert path.exists(), f"{path} doesn't exist"
-    assert "npy" in path.suffix, "Predictions should be stored as .npy files"
-    return np.load(path)
+    if path.suffix != ".npy":
+        raise ValueError(f"{path}: predictions are expected as .npy arrays")
+    if not path.is_file():
+        raise FileNotFoundError(path)
+    arr = np.load(path, allow_pickle=False)
+    if arr.ndim not in (2, 3):
+        raise ValueError(f"{path}: array of shape {arr.shape}, expected (N, classes) or (N, classes, steps)")
+    return arr
 
 
 def _launch(preds: Sequence[torch.Tensor], method: str, targets=None, want_fused=True):
@@ -36,8 +45,9 @@ def _launch(preds: Sequence[torch.Tensor], method: str, targets=None, want_fused
         raise ValueError("method must be 'add' or 'maximum'")
     if not 1 <= len(preds) <= 4:
         raise ValueError("1..4 prediction arrays expected")
-    shapes = {tuple(p.shape) for p in preds}
-    assert len(shapes) == 1, f"All preds should have the same shape but got {[tuple(p.shape) for p in preds]}"
+    if len({tuple(p.shape) for p in preds}) != 1:
+        # the reference asserts here (multi_stream_eval.py:35-38): same exception type
+        raise AssertionError(f"prediction arrays differ in shape: {[tuple(p.shape) for p in preds]}")
     for p in preds:
         native.require_device_f32(p, "prediction array")
     p0 = preds[0]
@@ -81,6 +91,6 @@ def multi_stream_eval(labels: str, pred1: str, pred2: str = None, pred3: str = N
     """File-level entry point with the reference's argument names (multi_stream_eval.py:45-62)."""
     paths = [p for p in (pred1, pred2, pred3, pred4) if p]
     preds = [torch.from_numpy(np.ascontiguousarray(load_preds(p), dtype=np.float32)).to(device) for p in paths]
-    targets = np.array(load_labels(labels))
+    targets = load_labels(labels)
     accs = topk_accuracies(preds, targets, (1, 3, 5), method)
     return {f"top{k}acc": v for k, v in zip((1, 3, 5), accs)}

@@ -4,8 +4,8 @@ Every clip / stream is independent through all ten blocks (eval-mode BN is a per
 cross-sample op), so the N axis is partitioned into contiguous slices, weights are replicated
 (12.6 MB) and continual state stays with its streams.  The one exchange step is an all-gather of the
 logits ``(N/world, classes)`` -- RCCL over xGMI when the process group is "nccl"; 240 KiB per rank at
-1024 clips/GPU, i.e. latency-bound, so it is issued as a single in-place collective on the compute
-stream.  The two skeletons (M) of a clip never split: sharding is over whole clips.
+1024 clips/GPU, i.e. latency-bound, so it is issued as ONE collective (torch.distributed orders it after the
+logits on the current stream and runs it on the process group's own stream; the next reader of the result waits on it).  The two skeletons (M) of a clip never split: sharding is over whole clips.
 """
 import ctypes
 import warnings

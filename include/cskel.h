@@ -9,8 +9,12 @@
  * Conventions
  *  - all tensors fp32, device (HBM) pointers, laid out exactly as the reference's contiguous tensors:
  *    clip activations (NM, C, T, V) with V innermost; "segment" = one of the NM skeleton sequences.
- *  - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous,
- *    no allocation and no synchronisation happens inside any call (graph-capture safe).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous.  The stage / step /
+ *    head entry points (csk_gcn_stage_f32 ... csk_fuse_rank_f32) neither allocate nor synchronise and are
+ *    graph-capture safe (the first launch of a kernel instantiation raises its LDS cap with hipFuncSetAttribute).
+ *    Exceptions: csk_stream_overlap_probe synchronises both streams it is given; csk_co_plan_create / _destroy
+ *    allocate host memory; csk_co_plan_cycle with graphs enabled (csk_co_plan_set_graphs, experimental) runs the
+ *    blocks on a stream owned by the plan, captures and instantiates hipGraphs, and fences with events.
  *  - packed weights are produced once on the host by continual-skeletons_amd/fold.py
  *    (BatchNorm(eval) + bias folding, zero padding of channel counts to CSK_CPAD / CSK_MT multiples).
  *  - return value: 0 = ok; <0 = argument error (see csk_last_error()); >0 = hipError_t of the launch.

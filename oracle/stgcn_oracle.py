@@ -191,6 +191,22 @@ def stgcn_forward(x: Tensor, sd: Dict[str, Tensor], gcn=graph_conv, taps=None) -
     return stgcn_head(h, sd, n, m)
 
 
+def co_stgcn_steps_pad_end(x: Tensor, sd: Dict[str, Tensor], pool_size: int, pool_padding: int, gcn=graph_conv) -> Tensor:
+    """What ``CoModelBase.forward_steps(x, pad_end=True)`` (models/base.py:187-190) yields from a clean state, written
+    in clip form: with ``pad_end`` every continual conv is flushed with its end padding, so each block emits exactly
+    the 'same'-padded clip block's frames (the identity of tests/test_cost_gcn.py:37-68 applied block by block);
+    ``spatial_pool`` per frame (base.py:84); ``AvgPool1d(pool_size, stride 1, padding pool_padding)`` with the zero
+    padding counted in the divisor (base.py:97: zero-initialised window in front, flushed zeros behind); ``Linear``
+    per step (base.py:99).  x: (N, C, T, V, M) -> (N, classes, n_predictions)."""
+    n, c, t, v, m = x.shape
+    h = stgcn_pre(x, sd)
+    for i, (_, _, stride, res) in enumerate(layer_table(c)):
+        h = st_block(h, sd, f"layers.layer{i + 1}.", stride, res, gcn=gcn)
+    f = h.view(n, m, h.shape[1], h.shape[2], v).mean(4).mean(1)                       # (N, 256, T')
+    pooled = F.avg_pool1d(f, pool_size, 1, padding=pool_padding, count_include_pad=True)
+    return torch.einsum("nct,kc->nkt", pooled, sd["fc.weight"]) + sd["fc.bias"][None, :, None]
+
+
 # --------------------------------------------------------------------------------------------
 # A-GCN adaptive graph convolution (reference: models/a_gcn/a_gcn.py:12-69)
 # --------------------------------------------------------------------------------------------

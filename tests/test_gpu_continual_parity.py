@@ -145,6 +145,27 @@ def test_costgcn_logits_vs_oracle_and_forward_modes():
     assert frame.shape == (1, 60) and max_err(frame, clip) <= TOL
 
 
+@pytest.mark.parametrize("native_plan", [True, False])
+def test_model_forward_steps_pad_end(native_plan):
+    """CoModelBase.forward_steps(x, pad_end=True) (models/base.py:187-190): flushing every block turns the stack into
+    the 'same'-padded clip stack and the pooling window gets its end padding -- the predictions must equal the
+    clip-form evaluation (oracle.co_stgcn_steps_pad_end: clip features, AvgPool1d with symmetric zero padding, fc);
+    update_state=False leaves the state where it was."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:1, :, :64].contiguous()
+    co = pkg.CoStGcn(A, pool_size=6, pool_padding=2).eval()
+    co.use_native_plan = native_plan
+    co.load_state_dict(sd, strict=True)
+    co = co.to(DEV)
+    with torch.no_grad():
+        want = o.co_stgcn_steps_pad_end(x, sd, 6, 2)                     # (1, 60, 16 + 4 - 6 + 1)
+    peek = co.forward_steps(x.to(DEV), pad_end=True, update_state=False).cpu()
+    got = co.forward_steps(x.to(DEV), pad_end=True).cpu()
+    assert got.shape == want.shape == (1, 60, 15)
+    assert max_err(got, want) <= TOL
+    assert torch.equal(peek, got)                                        # the peek ran from the same (clean) state
+
+
 def test_forward_cycle_equals_per_frame_stepping():
     """Batching the frames of a stride cycle into one launch per block must not change a single bit, for
     aligned cycles of 4 and 8 (the longest a launch takes), ragged cycle lengths and cycles that wrap the ring

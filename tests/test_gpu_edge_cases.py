@@ -180,3 +180,24 @@ def test_continual_block_random_sweep(seed):
     got = blk.to(DEV).forward_steps(x.to(DEV), pad_end=True).cpu()
     assert got.shape == want.shape, (ci, co, stride, res, T, N, v)
     assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max())), (ci, co, stride, res, T, N, v)
+
+
+def test_nan_propagates_through_relu_epilogues():
+    """torch.relu / np.maximum in the reference propagate NaN; the fused ReLU epilogues must not turn a NaN activation
+    into 0 (fmaxf would).  One NaN input element must surface as NaN in the outputs that depend on it, in clip and in
+    step mode, and everything else stays finite."""
+    A = pkg.ntu_graph().A
+    blk = pkg.SpatioTemporalBlock(4, 4, A).eval().to(DEV)
+    x = torch.rand(1, 4, 12, 25, device=DEV)
+    x[0, 2, 5, 7] = float("nan")
+    y = blk(x)
+    assert bool(torch.isnan(y[0, :, 5, 7]).all())                       # identity residual carries it straight through
+    assert bool(torch.isnan(y).any()) and bool(torch.isfinite(y[0, :, 0, 0]).all())
+    co = pkg.CoSpatioTemporalBlock(4, 4, A, padding=4).eval().to(DEV)
+    outs = []
+    for t in range(12):
+        o_ = co.forward_step(x[:, :, t].contiguous())
+        if o_ is not None:
+            outs.append(o_)
+    z = torch.stack(outs, dim=2)                                         # step s emits clip frame s - 4
+    assert bool(torch.isnan(z[0, :, 5, 7]).all()) and bool(torch.isfinite(z[0, :, 0, 0]).all())

@@ -179,3 +179,44 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(pkg.native, "LIB_PATH", "/nonexistent/libcskel_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pkg.native.lib()
+
+
+class _ForeignHparams:                                       # stands for Ride's AttributeDict & co. in a Lightning checkpoint
+    def __init__(self):
+        self.learning_rate = 0.1
+
+
+def test_lightning_style_checkpoint_with_hparams(tmp_path):
+    """a real Lightning / Ride .ckpt carries `hyper_parameters` objects.  argparse.Namespace loads under the
+    safe unpickler; any other class is refused with a message that says what to do; trusted=True loads it."""
+    import argparse
+
+    import torch
+    A = pkg.ntu_graph().A
+    src = pkg.StGcn(A)
+    ns, foreign = tmp_path / "ns.ckpt", tmp_path / "foreign.ckpt"
+    torch.save({"state_dict": src.state_dict(), "hyper_parameters": argparse.Namespace(graph="ntu_rgbd", lr=0.1)}, ns)
+    torch.save({"state_dict": src.state_dict(), "hyper_parameters": _ForeignHparams()}, foreign)
+    pkg.load_pretrained(pkg.CoStGcn(A), str(ns))
+    with pytest.raises(RuntimeError, match="trusted=True"):
+        pkg.load_pretrained(pkg.CoStGcn(A), str(foreign))
+    pkg.load_pretrained(pkg.CoStGcn(A), str(foreign), trusted=True)
+
+
+def test_fusion_file_loaders(tmp_path):
+    """.npy prediction arrays and the pickled (names, labels) label file of scripts/multi_stream_eval.py:16-31."""
+    import pickle
+
+    import numpy as np
+    from continual_skeletons_amd import fusion
+    np.save(tmp_path / "p.npy", np.zeros((3, 5), dtype=np.float32))
+    np.save(tmp_path / "bad.npy", np.zeros((3,), dtype=np.float32))
+    (tmp_path / "l.pkl").write_bytes(pickle.dumps((["a", "b", "c"], [4, 0, 2]), protocol=2))
+    assert fusion.load_preds(tmp_path / "p.npy").shape == (3, 5)
+    assert fusion.load_labels(tmp_path / "l.pkl").tolist() == [4, 0, 2]
+    with pytest.raises(ValueError):
+        fusion.load_preds(tmp_path / "bad.npy")
+    with pytest.raises(ValueError):
+        fusion.load_preds(tmp_path / "p.txt")
+    with pytest.raises(FileNotFoundError):
+        fusion.load_preds(tmp_path / "missing.npy")

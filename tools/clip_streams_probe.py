@@ -1,7 +1,7 @@
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _bootstrap; pkg = _bootstrap.load()
-sys.path.insert(0, '/root/repo'); import bench
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import bench
 dev = 'cuda:0'
 net = pkg.StGcn(pkg.ntu_graph().A).eval(); bench.randomise_(net, 0); net = net.to(dev)
 x = torch.rand((256, 3, 300, 25, 2), device=dev)
