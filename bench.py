@@ -93,23 +93,36 @@ def tcn_flops_per_clip_forward(nm, c_in=3, T=300, V=25):
     return 2 * macs * nm
 
 
-def _median_rate(fn, units, runs=5, warm=2, budget_s=30.0):
-    """Median of `runs` timed calls after `warm` untimed ones (SURVEY 8d / BASELINE.md 4 protocol); stops early (>= 3
-    runs) when the time budget is spent.  Returns (units per second, runs timed)."""
+CPU_THREAD_CAP = 16     # one thread count for both CPU legs: the oracle's torch-CPU ops stop scaling there, and a GPU box's
+                        # container can expose far more logical CPUs than its quota lets it run (oversubscribed OpenMP
+                        # teams then spin for minutes)
+
+
+def _median_rate(fn, units, runs=5, warm=2, budget_s=10.0):
+    """Median of `runs` timed calls after `warm` untimed ones (SURVEY 8d / BASELINE.md 4 protocol), inside a time
+    budget: the first (warm-up) call is timed and the number of further calls is cut to what the budget allows (at
+    least one timed call).  Returns (units per second, runs timed)."""
     import statistics
-    for _ in range(warm):
-        fn()
-    ts, t_all = [], time.perf_counter()
-    while len(ts) < runs and (len(ts) < 3 or time.perf_counter() - t_all < budget_s):
+    t0 = time.perf_counter()
+    fn()
+    first = time.perf_counter() - t0
+    afford = int(max(0.0, budget_s - first) / max(first, 1e-6))
+    if afford >= runs + warm - 1:
+        for _ in range(warm - 1):
+            fn()
+    runs = max(1, min(runs, afford))
+    ts = []
+    for _ in range(runs):
         t0 = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t0)
     return units / statistics.median(ts), len(ts)
 
 
-def cpu_baseline_clip(seed, threads):
+def cpu_baseline_clip(seed, threads, budget_s=30.0):
     """Oracle (CPU port of the reference op sequence) per the reference's own protocol (scripts/benchmark_all_ntu60.py:
-    15-18,52: batch 1; plus batch 8): median of 5 after 2 warm-ups, at all host threads and (batch 1) at one thread."""
+    15-18,52: batch 1; plus batch 8): median of 5 after 2 warm-ups, at `threads` threads and (batch 1) at one thread,
+    each leg inside its share of the time budget."""
     from oracle import stgcn_oracle as o
     import _bootstrap
     pkg = _bootstrap.load()
@@ -120,16 +133,16 @@ def cpu_baseline_clip(seed, threads):
     runs = {}
     with torch.no_grad():
         torch.set_num_threads(threads)
-        runs["batch8_all_threads"], n8 = _median_rate(lambda: o.stgcn_forward(x, sd), 8, budget_s=20.0)
-        runs["batch1_all_threads"], n1 = _median_rate(lambda: o.stgcn_forward(x[:1], sd), 1, budget_s=10.0)
+        runs["batch8"], n8 = _median_rate(lambda: o.stgcn_forward(x, sd), 8, budget_s=0.4 * budget_s)
+        runs["batch1"], n1 = _median_rate(lambda: o.stgcn_forward(x[:1], sd), 1, budget_s=0.2 * budget_s)
         torch.set_num_threads(1)
-        runs["batch1_one_thread"], n1t = _median_rate(lambda: o.stgcn_forward(x[:1], sd), 1, runs=3, warm=1, budget_s=25.0)
+        runs["batch1_one_thread"], n1t = _median_rate(lambda: o.stgcn_forward(x[:1], sd), 1, runs=3, warm=1, budget_s=0.4 * budget_s)
         torch.set_num_threads(threads)
-    best = max(runs["batch8_all_threads"], runs["batch1_all_threads"])
+    best = max(runs["batch8"], runs["batch1"])
     return dict(value=round(best, 3), unit="clips/s", cores=threads, kind="port",
                 runs={k: round(v, 3) for k, v in runs.items()},
                 sample=f"oracle.stgcn_forward, torch CPU fp32, NTU-60 clips; median of {n8} / {n1} / {n1t} timed passes "
-                       f"(batch 8 and batch 1 at {threads} threads, batch 1 at 1 thread) after warm-up; value = best of the all-thread runs")
+                       f"(batch 8 and batch 1 at {threads} threads, batch 1 at 1 thread) after warm-up; value = best of the {threads}-thread runs")
 
 
 def step_flops_per_cycle(nm, c_in=3, V=25):
@@ -187,10 +200,10 @@ def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, paral
     return dt, tcn_ms, n_launch, eng.state_bytes()
 
 
-def cpu_baseline_step(seed, threads):
+def cpu_baseline_step(seed, threads, budget_s=20.0):
     """Oracle continual path (port of the reference op sequence + restated continual protocol), one stream (batch 1, the
-    reference's protocol): 76 warm-up frames (models/base.py:144-159), then the median rate of 5 segments of 100
-    steady-state frames -- at all host threads and at one thread."""
+    reference's protocol): 76 warm-up frames (models/base.py:144-159), then the median rate of up to 5 segments of
+    steady-state frames (100 each when the time budget allows) -- at `threads` threads and at one thread."""
     from oracle import stgcn_oracle as o
     import _bootstrap
     import statistics
@@ -200,14 +213,20 @@ def cpu_baseline_step(seed, threads):
     sd = {k: v.clone() for k, v in pkg.StGcn(pkg.ntu_graph().A).state_dict().items()}
     sd.update({k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in net.state_dict().items()})
     x = torch.rand((1, NTU["C"], 200, NTU["V"], NTU["M"]), generator=torch.Generator().manual_seed(2))
+    info = {}
 
-    def rate(nthreads, segments, seg_frames):
+    def rate(tag, nthreads, budget):
         torch.set_num_threads(nthreads)
         orc = o.CoStGcnOracle(sd)
         rates = []
         with torch.no_grad():
+            t0 = time.perf_counter()
             for t in range(76):
                 orc.forward_step(x[:, :, t])
+            warm = time.perf_counter() - t0                      # early frames are cheaper (upper blocks idle): a lower bound
+            per_frame = max(warm / 76 * 1.5, 1e-5)
+            seg_frames = int(min(100, max(8, (budget - warm) / 5 / per_frame)))
+            segments = 5 if (budget - warm) / per_frame >= 5 * seg_frames else 3
             n = 0
             for _ in range(segments):
                 t0 = time.perf_counter()
@@ -215,15 +234,17 @@ def cpu_baseline_step(seed, threads):
                     orc.forward_step(x[:, :, 76 + n % 124])
                     n += 1
                 rates.append(seg_frames / (time.perf_counter() - t0))
+        info[tag] = (segments, seg_frames)
         return statistics.median(rates)
 
-    runs = {"all_threads": rate(threads, 5, 100), "one_thread": rate(1, 3, 60)}
+    runs = {"all_threads": rate("all_threads", threads, 0.6 * budget_s), "one_thread": rate("one_thread", 1, 0.4 * budget_s)}
     torch.set_num_threads(threads)
     best = max(runs, key=runs.get)          # tiny per-frame ops: one thread can beat the thread pool
     return dict(value=round(runs[best], 2), unit="frames/s", cores=threads if best == "all_threads" else 1, kind="port",
                 runs={k: round(v, 2) for k, v in runs.items()},
-                sample=f"oracle.CoStGcnOracle, one NTU-60 stream: 76 warm-up frames, then median of 5 segments of 100 "
-                       f"steady-state frames at {threads} threads (3 segments of 60 at 1 thread); value = the faster of the two")
+                sample=f"oracle.CoStGcnOracle, one NTU-60 stream: 76 warm-up frames, then median of {info['all_threads'][0]} segments "
+                       f"of {info['all_threads'][1]} steady-state frames at {threads} threads ({info['one_thread'][0]} x {info['one_thread'][1]} "
+                       f"at 1 thread); value = the faster of the two")
 
 
 def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2):
@@ -290,6 +311,7 @@ def main():
     ap.add_argument("--stream-shards", type=int, default=2, help="independent stream shards on separate HIP streams")
     ap.add_argument("--frames-per-launch", type=int, default=4, help="frames advanced per launch cycle of the online workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=50.0, help="seconds of CPU work the cpu_baseline legs may take in all")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -320,11 +342,11 @@ def main():
     do_clip, do_step = args.workload in ("both", "clip"), args.workload in ("both", "step")
     cpu = cpu_step = None
     if rank == 0 and not args.no_cpu_baseline:
-        host_threads = len(os.sched_getaffinity(0))         # one core count for both legs: every core of the host
+        host_threads = min(len(os.sched_getaffinity(0)), CPU_THREAD_CAP)       # one thread count for both legs
         if do_clip:
-            cpu = cpu_baseline_clip(seed=0, threads=host_threads)
+            cpu = cpu_baseline_clip(seed=0, threads=host_threads, budget_s=0.6 * args.cpu_budget)
         if do_step:
-            cpu_step = cpu_baseline_step(seed=0, threads=host_threads)
+            cpu_step = cpu_baseline_step(seed=0, threads=host_threads, budget_s=0.4 * args.cpu_budget)
 
     def max_over_ranks(v):
         t = torch.tensor([v], device=dev, dtype=torch.float64)

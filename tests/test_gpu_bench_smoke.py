@@ -23,7 +23,7 @@ def _run(*args):
 @pytest.mark.parametrize("workload", ["clip", "step"])
 def test_bench_line_contract(workload):
     d = _run("--workload", workload, "--batch", "4", "--streams", "8", "--steps", "2", "--warmup", "1", "--step-cycles", "2",
-             "--stream-shards", "2")
+             "--stream-shards", "2", "--cpu-budget", "6")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
