@@ -36,16 +36,23 @@ NTU = dict(C=3, T=300, V=25, M=2, classes=60)
 
 
 def randomise_(net, seed):
-    """Random-init weights of the named architecture with non-trivial BN statistics (data: synthetic)."""
+    """Random-init weights of the named architecture with non-trivial BN statistics (data: synthetic).  EVERY parameter
+    and buffer is drawn from the seeded generator (the constructors' own kaiming / normal inits use the unseeded global
+    RNG and would differ from rank to rank and from instance to instance)."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, prm in net.named_parameters():
+            if name.endswith(".A") or name == "A":
+                continue                                                   # the graph's adjacency
             if name.endswith("graph_attn"):
                 prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
             elif "bn" in name and name.endswith("weight"):
                 prm.copy_(torch.rand(prm.shape, generator=g) * 0.5 + 0.25)
             elif name.endswith("bias"):
                 prm.copy_(torch.rand(prm.shape, generator=g) * 0.2 - 0.1)
+            elif name.endswith("weight") and prm.dim() >= 2:              # conv / linear: kaiming-like, fan-in scaled
+                fan_in = prm[0].numel()
+                prm.copy_(torch.randn(prm.shape, generator=g) * (1.0 / fan_in) ** 0.5)
         for name, buf in net.named_buffers():
             if name.endswith("running_var"):
                 buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
@@ -93,9 +100,18 @@ def tcn_flops_per_clip_forward(nm, c_in=3, T=300, V=25):
     return 2 * macs * nm
 
 
-CPU_THREAD_CAP = 16     # one thread count for both CPU legs: the oracle's torch-CPU ops stop scaling there, and a GPU box's
-                        # container can expose far more logical CPUs than its quota lets it run (oversubscribed OpenMP
-                        # teams then spin for minutes)
+def host_cpu_threads(cap=16):
+    """Threads for both CPU baseline legs: the CPUs this process may really use -- the smaller of its affinity mask and
+    its cgroup CPU quota (a GPU box's container exposes 256 logical CPUs under a 16-CPU quota: an OpenMP team sized by
+    the mask would spin for minutes) -- and at most `cap`, where the oracle's torch-CPU ops stop scaling anyway."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
 
 
 def _median_rate(fn, units, runs=5, warm=2, budget_s=10.0):
@@ -342,7 +358,7 @@ def main():
     do_clip, do_step = args.workload in ("both", "clip"), args.workload in ("both", "step")
     cpu = cpu_step = None
     if rank == 0 and not args.no_cpu_baseline:
-        host_threads = min(len(os.sched_getaffinity(0)), CPU_THREAD_CAP)       # one thread count for both legs
+        host_threads = host_cpu_threads()                   # one thread count for both legs
         if do_clip:
             cpu = cpu_baseline_clip(seed=0, threads=host_threads, budget_s=0.6 * args.cpu_budget)
         if do_step:

@@ -47,6 +47,9 @@ mine = net(x[lo:hi].contiguous())
 gathered = parallel.all_gather_ragged(mine, 6)
 full = net(x)
 ok_clip = bool(torch.equal(gathered, full))
+if not ok_clip:
+    print(f"RANK{rank} clip: local-vs-full-slice max diff {float((mine - full[lo:hi]).abs().max())}, "
+          f"gathered-vs-full max diff {float((gathered - full).abs().max())}", flush=True)
 # ---- continual: 8 streams (ragged 7 as well), cycles of 4 frames until predictions appear
 ok_step = True
 for n_streams in (8, 7):
@@ -65,7 +68,10 @@ for n_streams in (8, 7):
         assert len(a) == len(b)
         for la, lb in zip(a, b):
             g = parallel.all_gather_ragged(la, n_streams)
-            ok_step = ok_step and bool(torch.equal(g, lb))
+            if not torch.equal(g, lb):
+                print(f"RANK{rank} step n={n_streams} cycle {c}: local-vs-slice {float((la - lb[lo:hi]).abs().max())}, "
+                      f"gathered-vs-whole {float((g - lb).abs().max())}", flush=True)
+                ok_step = False
             seen += 1
     ok_step = ok_step and seen > 0
 print(f"RANK{rank} clip={ok_clip} step={ok_step}", flush=True)
