@@ -159,12 +159,15 @@ class TemporalConvolution(_Folded):
         return tcn_stage(x, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.padding, relu=False)
 
 
-def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=None, w_res=None, res_off=0):
+def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=None, w_res=None, res_off=0, out=None):
     n, c, t_in, v = y.shape
     if t_in + 2 * pad < k:
         raise RuntimeError(f"temporal extent {t_in} (+2*{pad}) shorter than kernel {k}")
     t_out = (t_in + 2 * pad - k) // stride + 1
-    out = torch.empty((n, c_out, t_out, v), device=y.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, c_out, t_out, v), device=y.device, dtype=torch.float32)
+    elif tuple(out.shape) != (n, c_out, t_out, v) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != y.device:
+        raise RuntimeError(f"out must be a contiguous float32 {(n, c_out, t_out, v)} tensor on {y.device}")
     c_res, t_res = (x_res.shape[1], x_res.shape[2]) if x_res is not None else (0, 0)
     rc = native.lib().csk_tcn_stage_f32(
         native.ptr(y), native.ptr(w), native.ptr(x_res), native.ptr(w_res), native.ptr(bias), native.ptr(out),
@@ -208,7 +211,8 @@ class SpatioTemporalBlock(_Folded):
         sd = self.state_dict()
         return fold.fold_block_tail(sd, "", has_conv_residual=isinstance(self.residual, TemporalConvolution))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """``out`` (optional, native tail only): preallocated (N, C_out, T_out, V) tensor to write into."""
         self._require_eval()
         native.require_device_f32(x, "SpatioTemporalBlock input")
         y = self.gcn(x)                                   # GCN stage kernel (or any user GraphConv module)
@@ -226,7 +230,7 @@ class SpatioTemporalBlock(_Folded):
         else:
             mode, xr = 2, x
         return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
-                         res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink)
+                         res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out)
 
 
 def tcn_step_launch(*args):

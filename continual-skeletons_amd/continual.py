@@ -240,6 +240,8 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         if not 1 <= r <= MAX_CYCLE:
             raise ValueError(f"engine_advance handles 1..{MAX_CYCLE} frames per call, got {r}")
         s0, p = st.s, st.p
+        if not flush and self._fusable(r, s0, V):
+            return self._fused_advance(n_frames, V)
         f = 0
         while f < r:                               # per-frame graph conv, one launch per non-wrapping slot run
             s = s0 + f
@@ -269,6 +271,33 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             st.ksplit, native.ptr(st.partial) if st.partial is not None else None, native.stream_of(st.y))
         st.e += n_emit
         return slot0, n_emit
+
+    fuse_step = True    # one launch per block and stride cycle where csk_co_block_step_f32 applies (bit-identical)
+
+    def _fusable(self, r: int, s0: int, V: int) -> bool:
+        """csk_co_block_step_f32 (include/cskel.h): 64-row blocks, stride 1, a whole 4-frame cycle of emitting steps,
+        native sparse graph conv, block residual none / identity, no split-K."""
+        if not (self.fuse_step and r == 4 and self.stride == 1 and self.out_channels <= 64 and s0 >= self.delay
+                and self.kind in ("none", "identity") and type(self.gcn) is GraphConvolution and self._state.ksplit == 1):
+            return False
+        g = self.gcn._packed_ops(self._state.y.device)
+        cnt = g["ell_cnt_host"]
+        return int(cnt[0]) <= 1 and int(cnt[1]) <= 1 and int(cnt[2]) <= 4 and ((64 + V - 2) // V + 1) * V <= 128
+
+    def _fused_advance(self, n_skel: int, V: int):
+        st = self._state
+        g, t = self.gcn._packed_ops(st.y.device), self._packed_ops(st.y.device)
+        s0, slot0 = st.s, st.e % HIST
+        rc = native.lib().csk_co_block_step_f32(
+            native.ptr(st.xin), HIST, s0 % HIST, self.in_channels, native.ptr(g["w"]), native.ptr(g["bias"]),
+            native.ptr(g["ell_src"]), native.ptr(g["ell_val"]), native.ptr(g["ell_cnt_host"]), g["ell_w"], g["res_mode"],
+            native.ptr(st.y), YRING, s0 % YRING, native.ptr(t["w"]), native.ptr(t["bias"]),
+            {"none": 0, "identity": 1}[self.kind], (s0 - (self.kernel_size - 1) // 2) % HIST, native.ptr(st.out), HIST, slot0,
+            self.out_channels, n_skel, V, st.p, native.stream_of(st.y))
+        native.check(rc, "csk_co_block_step_f32")
+        st.s += 4
+        st.e += 4
+        return slot0, 4
 
     def _foreign_gcn_stage(self, st, s: int, run: int, n_frames: int, V: int):
         """Graph-conv modules without a native ``stage`` (e.g. the S-TR spatial attention a sibling model passes as
@@ -482,6 +511,8 @@ class CoStGcn(_Folded):
         self.__dict__["_plan_keep"] = (keep, self._weights_version())
         if self._plan_graphs:
             native.check(native.lib().csk_co_plan_set_graphs(plan, 1), "csk_co_plan_set_graphs")
+        fuse = all(self.layers[f"layer{i + 1}"].fuse_step for i in range(10))
+        native.check(native.lib().csk_co_plan_set_fusion(plan, int(fuse)), "csk_co_plan_set_fusion")
 
     def _refresh_plan_weights(self, device):
         """Weights were reloaded / edited in place: refold and hand the new operands to the plan; the

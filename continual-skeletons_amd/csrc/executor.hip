@@ -26,6 +26,7 @@ struct csk_co_plan {
     // key is run eagerly the first time, captured the second time, replayed afterwards.
     struct GraphSlot { hipGraphExec_t exec = nullptr; int seen = 0; };
     bool use_graphs = false;
+    bool fuse = true;          // csk_co_block_step_f32 for the blocks that qualify
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::unordered_map<std::string, GraphSlot> graphs;
@@ -104,6 +105,13 @@ extern "C" int csk_co_plan_set_graphs(csk_co_plan *plan, int enable) {
     return 0;
 }
 
+extern "C" int csk_co_plan_set_fusion(csk_co_plan *plan, int enable) {
+    if (!plan) CSK_FAIL("co_plan_set_fusion: null pointer");
+    plan->fuse = enable != 0;
+    plan->drop_graphs();                 // captured launch sequences differ
+    return 0;
+}
+
 extern "C" int csk_co_plan_counters(csk_co_plan *plan, int64_t *buf, int n, int set) {
     if (!plan || !buf) CSK_FAIL("co_plan_counters: null pointer");
     if (n != 2 + 2 * (int)plan->layers.size()) CSK_FAIL("co_plan_counters: expected %d values", 2 + 2 * (int)plan->layers.size());
@@ -128,9 +136,23 @@ extern "C" void csk_co_plan_reset(csk_co_plan *plan) {
 // one block: r frames are already in xin[(s .. s+r-1) % HIST]; returns emissions via *slot0 / *n_emit
 // (launch = false: only the counters advance -- the launches of this state are replayed from a captured graph)
 static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *xin, int r, int n_frames, int V,
-                         int64_t P, int *slot0, int *n_emit, bool launch, void *stream) {
+                         int64_t P, int *slot0, int *n_emit, bool launch, bool fuse, void *stream) {
     constexpr int K = 9, DELAY = 4, LAG = 4;      // padding="equal": delay = k-1-p = 4; residual lag (k-1)/2
     const long s0 = c.s;
+    // one fused launch for a whole emitting 4-frame cycle of a 64-row block (continual.py:_fusable)
+    if (fuse && r == 4 && l.stride == 1 && l.c_out <= 64 && s0 >= DELAY && l.res_kind != CSK_RES_CONV && l.tcn_ksplit <= 1 &&
+        l.ell_cnt[0] <= 1 && l.ell_cnt[1] <= 1 && l.ell_cnt[2] <= 4 && ((64 + V - 2) / V + 1) * V <= 128) {
+        *slot0 = (int)(c.e % CSK_CO_HIST);
+        const int rc = !launch ? 0 : csk_co_block_step_f32(xin, CSK_CO_HIST, (int)(s0 % CSK_CO_HIST), l.c_in, l.gcn_w, l.gcn_bias,
+                                         l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, l.gcn_res_mode, l.y_ring, CSK_CO_YRING,
+                                         (int)(s0 % CSK_CO_YRING), l.tcn_w, l.tcn_bias, l.res_kind,
+                                         (int)((s0 - LAG) % CSK_CO_HIST), l.out_ring, CSK_CO_HIST, *slot0, l.c_out, n_frames, V, P,
+                                         stream);
+        if (rc) return rc;
+        c.s += 4; c.e += 4;
+        *n_emit = 4;
+        return 0;
+    }
     for (int f = 0; f < r;) {                      // per-frame graph conv, one launch per non-wrapping slot run
         const long s = s0 + f;
         int run = r - f;
@@ -169,7 +191,7 @@ static int run_blocks(csk_co_plan *p, int r, bool launch, int *slot0, int *n_las
     *n_last = 0;
     for (size_t i = 0; i < p->layers.size(); ++i) {
         int ne = 0;
-        const int rc = advance_block(p->layers[i], p->cnt[i], xin, rr, p->N * p->M, p->V, p->P, slot0, &ne, launch, stream);
+        const int rc = advance_block(p->layers[i], p->cnt[i], xin, rr, p->N * p->M, p->V, p->P, slot0, &ne, launch, p->fuse, stream);
         if (rc) return rc;
         if (ne == 0) return 0;
         rr = ne;

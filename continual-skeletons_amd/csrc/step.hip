@@ -93,7 +93,7 @@ struct StepParams {
 // (1, or 2 for a stride-2 block; only meaningful for E > 1).  SPLIT = false is the throughput kernel; the split-K form
 // is a separate instantiation (E = 1) so that its extra index arithmetic costs the default path nothing.
 template <int MT, int E, int HS, bool SPLIT>
-__global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
+__device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx, const int by, const int bz, float *smem) {
     constexpr int NT = 16384 / MT;
     constexpr int NP = NT / E;                      // positions per tile
     constexpr int NS = 8 + (E - 1) * HS + 1;        // window slots staged per chunk (K = 9)
@@ -101,21 +101,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     static_assert(NP >= 64, "a wave's 64 columns must belong to one emission");
     typedef RingStage<NP, NS> Stage;
     constexpr int NU_RES = (E * KC + Stage::RPU - 1) / Stage::RPU;      // sweeps of the residual-conv phase (E slots)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem;                       // [K][KC][MT]
     float *Bl = smem + 9 * KC * MT;         // [NS (+ sweep padding)][KC][NP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * MT, p0 = blockIdx.x * NP;
+    const int m0 = by * MT, p0 = bx * NP;
     const int64_t P = p.P;
-    // emission group of this workgroup (blockIdx.z): emissions j0 .. j0+E-1 of the launch; emission j has its newest
+    // emission group of this workgroup (bz = blockIdx.z): emissions j0 .. j0+E-1 of the launch; emission j has its newest
     // frame in slot head + j*head_step, its residual frame in xres slot xres_slot0 + j*xres_step and goes to out slot
     // out_slot0 + j (all modulo their ring depths)
     constexpr bool split = SPLIT;
-    const int ks = split ? (int)blockIdx.z % p.ksplit : 0;
-    const int j0 = (split ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z) * E;
+    const int ks = split ? bz % p.ksplit : 0;
+    const int j0 = (split ? bz / p.ksplit : bz) * E;
     const int jw = j0 + (wn * 64) / NP;                       // emission of this wave's 64 columns (wave-uniform)
     const int cb = ks * p.cper;                               // first channel of this split
     const int Cl = split ? min(p.C - cb, p.cper) : p.C;       // its channels (<= 0: padding-only split, sums stay zero)
@@ -289,6 +288,241 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     }
 }
 
+template <int MT, int E, int HS, bool SPLIT>
+__global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    tcn_step_tile<MT, E, HS, SPLIT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused continual block: GCN stage + TCN step of one CoSpatioTemporalBlock in ONE launch (models/base.py:412-446 is one
+// forward_step).  For blocks with C_out <= 64 and stride 1 advancing a full stride cycle of E = 4 frames:
+//   a workgroup owns NP = 64 positions of all four new frames.
+//   phase G  wave w computes the post-GCN frame w at these positions (64 channels x 64 positions, K = R*C_in):
+//            weights staged per 8-channel chunk for the whole workgroup, the wave's own input rows (all joints of the
+//            <= 4 skeletons its positions touch) in a private LDS strip, aggregation formed on the fly from
+//            register-resident adjacency entries exactly as in gcn_stage_sparse2_kernel (same summation order);
+//            y = ReLU(acc + bias + gcn_residual) goes to the y-ring slot of frame w (it is state: later cycles need it).
+//   hand-off the four new slots are read back by phase T through L2 (no HBM round trip): stores retired
+//            (s_waitcnt), workgroup barrier, L1 invalidated (other workgroups of this CU may have pulled lines that
+//            straddle the tile edge before they were written).
+//   phase T  tcn_step_tile<64, 4, 1>: the 12-slot window (8 old + 4 new) serves the 4 x 9 taps; residual and output as
+//            in the two-launch form.
+// There is no temporal halo in step mode, so nothing is recomputed; what the fusion buys is one launch (and one
+// partially filled tail round) per block instead of two, and the new frames' y read from L2 instead of HBM.  Measured
+// (tools/online_pass.py [--no-fuse], 1024 streams): performance-neutral, 943-951 k vs 942-948 k frames/s with two
+// stream shards, 817-820 k vs 819-822 k with one -- with two shards the GPU already runs two kernels 94 % of the time,
+// so neither the saved launch nor the saved HBM read is on the critical path.  Kept as the default form of the blocks it
+// covers because it is what models/base.py:412-446 is (one forward_step) and it halves their launch count.
+// ------------------------------------------------------------------------------------------------
+struct CoBlockParams {
+    StepParams t;                        // phase T (ring = the y ring; head = slot of the first new frame)
+    const float *xin;                    // block input ring [xin_slots][Cin][P]; new frame f in slot (xin_slot0 + f) % xin_slots
+    const float *gw, *gbias;             // packed GCN operands (csk_gcn_stage_f32)
+    const int32_t *ell_src;
+    const float *ell_val;
+    int ell_cnt[3], ell_w;
+    int xin_slots, xin_slot0, Cin, CinPad, V, n_skel, ldbx, fast_epi_g;
+    unsigned vmagic;
+};
+
+// (two workgroups per CU: 176 registers; cut to 168 for three per CU it spills 8-11 registers and measures the same)
+template <bool CONVRES>
+__global__ __launch_bounds__(NTHREADS, 2) void co_block_kernel(const CoBlockParams p) {
+    constexpr int MT = 64, NP = 64, E = 4, KCG8 = 8;
+    constexpr int R = CONVRES ? 4 : 3;
+    constexpr int M4 = MT / 4;
+    constexpr int WB = (R * KCG8 * M4 + NTHREADS - 1) / NTHREADS;   // 2
+    constexpr int NJ = 2;                                           // 64-lane sweeps per private activation row (<= 128 positions)
+    constexpr int NS = KCG8 / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int p0 = blockIdx.x * NP;
+    const int64_t P = p.t.P;
+    const int V = p.V, Q = p.n_skel * V;                            // valid positions (P is Q rounded up to 4)
+    {   // ---------------- phase G: frame `wave`
+        const int wsz = R * KCG8 * MT, xsz = E * KCG8 * p.ldbx, bufsz = wsz + xsz;   // chunk buffer: Wl, then 4 private strips
+        const int qend = min(p0 + NP, Q);
+        const int ta = div_magic(min(p0, Q - 1), p.vmagic), tb = div_magic(max(qend, 1) - 1, p.vmagic);
+        const int span = (tb - ta + 1) * V;
+        int eoff[2][6], ioff[2];
+        float eval[2][6];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int q = min(p0 + ni * 32 + l31, Q - 1);
+            const int t = div_magic(q, p.vmagic);
+            const int w = q - t * V, fb = max(t - ta, 0) * V;
+            ioff[ni] = fb + w;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;
+                const bool have = k < p.ell_cnt[r];
+                const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
+                eoff[ni][e] = fb + (have ? p.ell_src[idx] : 0);
+                eval[ni][e] = have ? p.ell_val[idx] : 0.f;
+            }
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+        const float *xf = p.xin + (int64_t)((p.xin_slot0 + wave) % p.xin_slots) * p.Cin * P;     // this wave's frame
+        f32x4 wv[WB];
+        unsigned wgo[WB], wlo[WB];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+            const int e = min(u * NTHREADS + tid, R * KCG8 * M4 - 1);
+            const int row = e / M4, m4 = e % M4;
+            wgo[u] = (unsigned)(((row / KCG8) * p.CinPad + (row % KCG8)) * p.t.Mpad + m4 * 4);
+            wlo[u] = (unsigned)(e * 4);
+        }
+        float bv[KCG8][NJ];
+        unsigned bgo[NJ], blo[NJ];
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            const int j = min(u * 64 + lane, span - 1);
+            bgo[u] = (unsigned)min(ta * V + j, Q - 1);
+            blo[u] = (unsigned)j;
+        }
+        auto issue_all = [&](int c0) {
+#pragma unroll
+            for (int u = 0; u < WB; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(p.gw + (size_t)c0 * p.t.Mpad + wgo[u]);
+#pragma unroll
+            for (int kk = 0; kk < KCG8; ++kk) {
+                const int c = min(c0 + kk, p.Cin - 1);             // clamped: padding channels carry zero weights
+#pragma unroll
+                for (int u = 0; u < NJ; ++u) bv[kk][u] = (xf + (int64_t)c * P)[bgo[u]];
+            }
+        };
+        auto commit = [&](float *buf) {
+#pragma unroll
+            for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(buf + wlo[u]) = wv[u];
+            float *dst = buf + wsz + wave * (KCG8 * p.ldbx);
+#pragma unroll
+            for (int kk = 0; kk < KCG8; ++kk)
+#pragma unroll
+                for (int u = 0; u < NJ; ++u) dst[kk * p.ldbx + blo[u]] = bv[kk][u];
+        };
+        auto mfma_step = [&](const float *buf, int s) {
+            const float *Wl = buf, *Bx = buf + wsz + wave * (KCG8 * p.ldbx);
+            const int kk = 2 * s + kh;
+            const float *bx = Bx + kk * p.ldbx;
+            float b[R][2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                b[0][ni] = eval[ni][0] * bx[eoff[ni][0]];
+                b[1][ni] = eval[ni][1] * bx[eoff[ni][1]];
+                float s2 = eval[ni][2] * bx[eoff[ni][2]];
+                s2 = fmaf(eval[ni][3], bx[eoff[ni][3]], s2);
+                s2 = fmaf(eval[ni][4], bx[eoff[ni][4]], s2);
+                s2 = fmaf(eval[ni][5], bx[eoff[ni][5]], s2);
+                b[2][ni] = s2;
+                if (CONVRES) b[R - 1][ni] = bx[ioff[ni]];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float *wr = Wl + (r * KCG8 + kk) * MT + l31;
+                const float a0 = wr[0], a1 = wr[32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][1], acc[1][1], 0, 0, 0);
+            }
+        };
+        const int nchunks = p.CinPad / KCG8;
+        issue_all(0);
+        commit(smem);
+        if (nchunks > 1) issue_all(KCG8);
+        __syncthreads();
+        for (int c = 0; c + 1 < nchunks; ++c) {
+            float *cur = smem + (c & 1) * bufsz, *oth = smem + ((c & 1) ^ 1) * bufsz;
+            commit(oth);
+            issue_all(min(c + 2, nchunks - 1) * KCG8);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) mfma_step(cur, s);
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+        }
+        {
+            const float *last = smem + ((nchunks - 1) & 1) * bufsz;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) mfma_step(last, s);
+        }
+        // y = ReLU(acc + bias + identity gcn_residual) -> y ring slot of this wave's frame
+        float *yf = p.t.ring == nullptr ? nullptr
+                                        : const_cast<float *>(p.t.ring) + (int64_t)((p.t.head + wave) % p.t.slots) * p.t.C * P;
+        const bool full = p.fast_epi_g && MT <= p.t.C;
+        const unsigned kh4 = 4u * (unsigned)kh;
+        const int qb = p0 + lane;
+        const bool qv = qb < Q;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            float bb[16], rv[2][16];
+            if (full) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) bb[g] = ld_lane(p.gbias + (mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const unsigned lo = 4u * (kh4 * (unsigned)P + (unsigned)min(p0 + ni * 32 + l31, Q - 1));
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        rv[ni][g] = CONVRES ? 0.f : ld_lane(xf + (int64_t)(mi * 32 + (g & 3) + 8 * (g >> 2)) * P, lo);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) bb[g] = p.gbias[mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int qc = min(p0 + ni * 32 + l31, Q - 1);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int co = mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                        rv[ni][g] = CONVRES ? 0.f : xf[(int64_t)min(co, p.t.C - 1) * P + qc];
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float v0 = relu_nan(acc[mi][0][g] + bb[g] + rv[0][g]);
+                const float v1 = relu_nan(acc[mi][1][g] + bb[g] + rv[1][g]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                acc[mi][0][g] = __uint_as_float(sw[0]);
+                acc[mi][1][g] = __uint_as_float(sw[1]);
+            }
+            if (full) {
+                if (qv) {
+                    const unsigned qo = 4u * (unsigned)qb;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        float *orow = yf + (int64_t)(mi * 32 + (g & 3) + 8 * (g >> 2)) * P;
+                        st_lane(orow, qo, acc[mi][0][g]);
+                        st_lane(orow + 4 * P, qo, acc[mi][1][g]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row0 = mi * 32 + (g & 3) + 8 * (g >> 2);
+                    if (qv && row0 < p.t.C) yf[(int64_t)row0 * P + qb] = acc[mi][0][g];
+                    if (qv && row0 + 4 < p.t.C) yf[(int64_t)(row0 + 4) * P + qb] = acc[mi][1][g];
+                }
+            }
+        }
+    }
+    // ---------------- hand-off: the new y frames become visible to every wave of this workgroup
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // this wave's y stores have retired
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // drop L1 lines that were pulled before the stores
+    // ---------------- phase T
+    tcn_step_tile<64, 4, 1, false>(p.t, (int)blockIdx.x, 0, 0, smem);
+}
+
 // split-K reduction: out_j[co][p] = ReLU?( sum_ks part[j*ksplit + ks][co][p] (fixed order) + bias[co] + identity residual )
 __global__ __launch_bounds__(256) void step_reduce_kernel(const StepParams p) {
     const int64_t P = p.P, P4 = P / 4;
@@ -405,6 +639,54 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
         const int64_t work = (int64_t)c_out * (P / 4);
         hipLaunchKernelGGL(step_reduce_kernel, dim3((unsigned)((work + 255) / 256), n_emit), dim3(256), 0, s, p);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_co_block_step_f32(const float *xin, int xin_slots, int xin_slot0, int c_in, const float *gcn_w,
+                                     const float *gcn_bias, const int32_t *ell_src, const float *ell_val,
+                                     const int32_t *ell_cnt, int ell_w, int gcn_res_mode, float *y_ring, int y_slots,
+                                     int y_slot0, const float *tcn_w, const float *tcn_bias, int res_mode, int x_res_slot0,
+                                     float *out, int out_slots, int out_slot0, int c_out, int n_skel, int V, int64_t P,
+                                     void *stream) {
+    if (!xin || !gcn_w || !gcn_bias || !ell_src || !ell_val || !ell_cnt || !y_ring || !tcn_w || !tcn_bias || !out)
+        CSK_FAIL("co_block_step: null pointer");
+    if (c_in <= 0 || c_out <= 0 || c_out > 64 || n_skel <= 0 || V < 2 || V > 64 || P < (int64_t)n_skel * V || (P & 3) || P < 4)
+        CSK_FAIL("co_block_step: bad dims (c_out <= 64, P a multiple of 4 holding n_skel * V positions)");
+    if (P >= (1ll << 31) - 256) CSK_FAIL("co_block_step: P too large");
+    if (xin_slots < 8 || y_slots < 12 || out_slots < 4) CSK_FAIL("co_block_step: rings too shallow for a 4-frame cycle");
+    if (xin_slot0 < 0 || xin_slot0 >= xin_slots || y_slot0 < 0 || y_slot0 >= y_slots || out_slot0 < 0 || out_slot0 >= out_slots ||
+        x_res_slot0 < 0 || x_res_slot0 >= xin_slots)
+        CSK_FAIL("co_block_step: slot index out of range");
+    if (gcn_res_mode != CSK_RES_IDENTITY && gcn_res_mode != CSK_RES_CONV) CSK_FAIL("co_block_step: gcn_res_mode must be identity or conv");
+    if (gcn_res_mode == CSK_RES_IDENTITY && c_in != c_out) CSK_FAIL("co_block_step: identity gcn residual needs c_in == c_out");
+    if (res_mode != CSK_RES_NONE && res_mode != CSK_RES_IDENTITY) CSK_FAIL("co_block_step: block residual must be none or identity");
+    if (res_mode == CSK_RES_IDENTITY && c_in != c_out) CSK_FAIL("co_block_step: identity block residual needs c_in == c_out");
+    if (ell_w < 1 || ell_w > V || ell_cnt[0] < 0 || ell_cnt[0] > 1 || ell_cnt[1] < 0 || ell_cnt[1] > 1 || ell_cnt[2] < 0 || ell_cnt[2] > 4 ||
+        ell_cnt[2] > ell_w)
+        CSK_FAIL("co_block_step: needs a skeleton-sparse adjacency (<= 1/1/4 non-zeros per column)");
+    if (((uintptr_t)xin | (uintptr_t)y_ring | (uintptr_t)out) & 15) CSK_FAIL("co_block_step: state pointers must be 16-byte aligned");
+    constexpr int NP = 64;
+    CoBlockParams p;
+    StepParams &t = p.t;
+    t.ring = y_ring; t.w = tcn_w; t.xres = xin; t.wres = nullptr; t.bias = tcn_bias; t.out = out;
+    t.C = c_out; t.Cpad = round_up(c_out, CSK_CPAD); t.Cout = c_out; t.Mpad = round_up(c_out, CSK_MT);
+    t.K = 9; t.slots = y_slots; t.head = y_slot0; t.head_step = 1; t.res_mode = res_mode;
+    t.Cres = res_mode ? c_in : 1; t.CresPad = round_up(t.Cres, CSK_CPAD); t.relu = 1; t.P = P;
+    t.fast_epi = P < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
+    t.xres_slots = xin_slots; t.xres_slot0 = x_res_slot0; t.xres_step = 1; t.out_slots = out_slots; t.out_slot0 = out_slot0;
+    t.ksplit = 1; t.cper = t.Cpad; t.part = nullptr;
+    p.xin = xin; p.gw = gcn_w; p.gbias = gcn_bias; p.ell_src = ell_src; p.ell_val = ell_val;
+    for (int i = 0; i < 3; ++i) p.ell_cnt[i] = ell_cnt[i];
+    p.ell_w = ell_w; p.xin_slots = xin_slots; p.xin_slot0 = xin_slot0; p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD);
+    p.V = V; p.n_skel = n_skel; p.vmagic = vmagic_of(V); p.fast_epi_g = t.fast_epi;
+    p.ldbx = round_up(((NP + V - 2) / V + 1) * V, 4);
+    if (p.ldbx > 128) CSK_FAIL("co_block_step: %d joints per skeleton make the input strip of a 64-position tile longer than 128", V);
+    const int R = gcn_res_mode == CSK_RES_CONV ? 4 : 3;
+    const size_t lds_g = 2 * (size_t)(R * 8 * 64 + 4 * 8 * p.ldbx), lds_t = (size_t)(9 * KC * 64) + RingStage<64, 12>::LDS_FLOATS;
+    const size_t lds = (lds_g > lds_t ? lds_g : lds_t) * sizeof(float);
+    void (*kern)(CoBlockParams) = R == 4 ? co_block_kernel<true> : co_block_kernel<false>;
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((P + NP - 1) / NP)), dim3(NTHREADS), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

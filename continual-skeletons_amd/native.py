@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 # name -> argtypes; mirrors include/cskel.h line by line
@@ -25,6 +25,7 @@ SIGNATURES = {
     "csk_pool_scaled_f32": [_p, _p, _i, _i, _i, _i, C.c_float, _p],
     "csk_agcn_attention_f32": [_p, _p, _p, _i, _i, _i, _i, _l, _l, _i, _l, _p],
     "csk_tcn_step_f32": [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _p, _p],
+    "csk_co_block_step_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _l, _p],
     "csk_co_spatial_pool_f32": [_p, _p, _i, _i, _i, _l, _p],
     "csk_co_window_mean_f32": [_p, _p, _l, _i, _i, _i, _p],
 
@@ -35,6 +36,7 @@ SIGNATURES = {
     "csk_co_plan_reset": [_p],
     "csk_co_plan_counters": [_p, C.POINTER(C.c_int64), _i, _i],
     "csk_co_plan_set_graphs": [_p, _i],
+    "csk_co_plan_set_fusion": [_p, _i],
     "csk_co_plan_cycle": [_p, _p, _i, _p, _p, _p, _p, _p],
 }
 RESTYPES = {"csk_co_plan_create": C.c_void_p, "csk_co_plan_destroy": None, "csk_co_plan_reset": None}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 7
+#define CSK_ABI_VERSION 8
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -177,6 +177,26 @@ int csk_tcn_step_f32(const float *ring, int slots, int head, int head_step, int 
                      int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, int ksplit, float *partial,
                      void *stream);
 
+/*
+ * One CoSpatioTemporalBlock.forward_step cycle in ONE launch (models/base.py:412-446): graph conv of the 4 new frames of
+ * a stride cycle + the 4 emitting steps of the temporal conv + residual + ReLU -- csk_gcn_stage_f32 followed by
+ * csk_tcn_step_f32 with n_emit = 4, fused (same arithmetic, same summation order, bit-identical results).  For blocks
+ * with c_out <= 64, temporal stride 1, k = 9, a skeleton-sparse adjacency (ell_cnt <= 1/1/4) and a block residual that
+ * is absent (CSK_RES_NONE) or the identity; all 4 frames must emit (the block has seen >= 4 frames before).
+ *  xin     block input ring [xin_slots][c_in][P]; new frame f = 0..3 in slot (xin_slot0 + f) mod xin_slots; the residual
+ *          frame of emission j in slot (x_res_slot0 + j) mod xin_slots (the input delayed by 4 frames)
+ *  y_ring  [y_slots][c_out][P] post-GCN frames, y_slots >= 12; new frame f is WRITTEN to slot (y_slot0 + f) mod y_slots,
+ *          the temporal window of emission j is slots y_slot0 + j - 8 .. y_slot0 + j
+ *  out     [out_slots][c_out][P]; emission j goes to slot (out_slot0 + j) mod out_slots
+ *  n_skel  skeletons per frame (streams * M); P >= n_skel * V, a multiple of 4
+ *  gcn_* / ell_* / tcn_*: the packed operands of csk_gcn_stage_f32 / csk_tcn_step_f32.
+ */
+int csk_co_block_step_f32(const float *xin, int xin_slots, int xin_slot0, int c_in, const float *gcn_w,
+                          const float *gcn_bias, const int32_t *ell_src, const float *ell_val, const int32_t *ell_cnt,
+                          int ell_w, int gcn_res_mode, float *y_ring, int y_slots, int y_slot0, const float *tcn_w,
+                          const float *tcn_bias, int res_mode, int x_res_slot0, float *out, int out_slots, int out_slot0,
+                          int c_out, int n_skel, int V, int64_t P, void *stream);
+
 /* spatial_pool of CoModelBase (models/base.py:84) on a channel-major frame: feat[n, c] = mean of the MV = M*V
  * positions of stream n.  h (C, P); feat (N, C). */
 int csk_co_spatial_pool_f32(const float *h, float *feat, int N, int C, int MV, int64_t P, void *stream);
@@ -245,6 +265,9 @@ int csk_co_plan_counters(csk_co_plan *plan, int64_t *buf, int n, int set);
  * The blocks then run on a stream owned by the plan, fenced against the caller's stream by events; input
  * normalisation and the head stay ordinary launches.  Same kernels, same arguments: bit-identical results. */
 int csk_co_plan_set_graphs(csk_co_plan *plan, int enable);
+/* 1 (default): blocks that qualify advance a 4-frame cycle with one csk_co_block_step_f32 launch instead of a
+ * csk_gcn_stage_f32 + csk_tcn_step_f32 pair (bit-identical results); 0: always the two-launch form. */
+int csk_co_plan_set_fusion(csk_co_plan *plan, int enable);
 /* Advance by r = 1..CSK_CO_MAX_CYCLE frames, frames[i] = (N, C, V, M) device pointers.  On return
  * *last_slot / *n_feat describe the last layer's emissions of this cycle (slot of the first, count) and
  * *n_logits how many predictions were written to `logits` ([CSK_CO_MAX_CYCLE][N][classes], slice j = prediction j). */

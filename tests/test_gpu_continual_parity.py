@@ -355,3 +355,68 @@ def test_latency_mode_split_k_matches_oracle_and_default(native_plan):
         r0, r1 = big[0].forward_step(frames[t]), big[1].forward_step(frames[t])
         assert (r0 is None) == (r1 is None) and (r0 is None or torch.equal(r0, r1))
     assert all(big[1].layers[f"layer{i + 1}"]._state.ksplit == 1 for i in range(10))
+
+
+def _set_fusion(model, on):
+    for i in range(10):
+        model.layers[f"layer{i + 1}"].fuse_step = on
+    model._n = None                                  # re-bind (the native plan reads the flag when it is built)
+
+
+@pytest.mark.parametrize("graph,n", [("ntu", 5), ("kinetics", 3)])
+@pytest.mark.parametrize("native_plan", [True, False])
+def test_fused_block_step_equals_two_launch_form(graph, n, native_plan):
+    """csk_co_block_step_f32 (GCN stage + TCN step of a block in one launch; layers 1-4 of the stack) against the
+    two-launch form: logits AND every state ring bit-identical over many 4-frame cycles; ragged position counts
+    (5 streams x 2 x 25 = 250, 3 x 2 x 18 = 108)."""
+    A_ = (pkg.ntu_graph() if graph == "ntu" else pkg.kinetics_graph()).A
+    v = A_.shape[-1]
+    torch.manual_seed(3)
+    fused = pkg.CoStGcn(A_, input_shape=(3, 300, v, 2), pool_size=3, pool_padding=1).eval()
+    plain = pkg.CoStGcn(A_, input_shape=(3, 300, v, 2), pool_size=3, pool_padding=1).eval()
+    import bench
+    bench.randomise_(fused, 5)
+    plain.load_state_dict(fused.state_dict())
+    fused.use_native_plan = plain.use_native_plan = native_plan
+    _set_fusion(fused, True)
+    _set_fusion(plain, False)
+    fused, plain = fused.to(DEV), plain.to(DEV)
+    frames = torch.rand((4 * 26, n, 3, v, 2), generator=torch.Generator().manual_seed(9)).to(DEV)
+    n_pred = 0
+    for c in range(26):
+        fr = [frames[4 * c + f] for f in range(4)]
+        a, b = fused.forward_cycle(fr), plain.forward_cycle(fr)
+        assert len(a) == len(b)
+        for la, lb in zip(a, b):
+            assert torch.equal(la, lb)
+            n_pred += 1
+        for i in (1, 2, 3, 4):
+            sa, sb = fused.layers[f"layer{i}"]._state, plain.layers[f"layer{i}"]._state
+            assert torch.equal(sa.y, sb.y) and torch.equal(sa.out, sb.out), (c, i)
+    assert n_pred >= 3
+
+
+@pytest.mark.parametrize("ci,co,res", [(4, 4, True), (6, 6, False), (3, 8, False), (64, 64, True)])
+def test_fused_block_step_small_and_ragged_channels(ci, co, res):
+    """Block level, channel counts below the 64-row tile (general epilogue path) and a conv gcn_residual: engine_advance
+    of a whole cycle, fused against unfused, rings bit-identical; 7 skeletons (P = 176 of 175 positions)."""
+    torch.manual_seed(1)
+    a = pkg.CoSpatioTemporalBlock(ci, co, A, residual=res, padding="equal").eval()
+    import bench
+    bench.randomise_(a, 2)
+    b = pkg.CoSpatioTemporalBlock(ci, co, A, residual=res, padding="equal").eval()
+    b.load_state_dict(a.state_dict())
+    a, b = a.to(DEV), b.to(DEV)
+    a.fuse_step, b.fuse_step = True, False
+    n_skel, p = 7, 176
+    sa, sb = a.bind_state(p, torch.device(DEV)), b.bind_state(p, torch.device(DEV))
+    g = torch.Generator().manual_seed(4)
+    for cyc in range(9):
+        x = torch.rand((4, ci, p), generator=g).to(DEV)
+        for st in (sa, sb):
+            for f in range(4):
+                st.xin[(st.s + f) % 16] = x[f]
+        ra, rb = a.engine_advance(4, n_skel, 25), b.engine_advance(4, n_skel, 25)
+        assert ra == rb
+        assert torch.equal(sa.y, sb.y) and torch.equal(sa.out, sb.out), cyc
+    assert ra is not None and ra[1] == 4

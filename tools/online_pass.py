@@ -21,6 +21,7 @@ ap.add_argument("--fpl", type=int, default=4)
 ap.add_argument("--cycles", type=int, default=24)
 ap.add_argument("--streams", type=int, default=1024)
 ap.add_argument("--warm-cycles", type=int, default=0, help="default: enough to fill the stack and the temporal pool")
+ap.add_argument("--no-fuse", action="store_true", help="two launches per block everywhere (no csk_co_block_step_f32)")
 args = ap.parse_args()
 
 pkg = _bootstrap.load()
@@ -32,6 +33,9 @@ dev = torch.device("cuda:0")
 def make():
     net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
     bench.randomise_(net, seed=0)
+    if args.no_fuse:
+        for blk in net.layers.values():
+            blk.fuse_step = False
     return net.to(dev)
 
 
@@ -57,5 +61,5 @@ for _ in range(args.cycles):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 assert out is not None and bool(torch.isfinite(out).all())
-print(f"ONLINE_PASS shards={args.shards} fpl={args.fpl} streams={args.streams} warm_cycles={warm} cycles={args.cycles} "
+print(f"ONLINE_PASS fused={not args.no_fuse} shards={args.shards} fpl={args.fpl} streams={args.streams} warm_cycles={warm} cycles={args.cycles} "
       f"ms_per_cycle={dt / args.cycles * 1e3:.4f} frames_per_s={args.fpl * args.streams * args.cycles / dt:.0f}")
