@@ -161,19 +161,6 @@ def cpu_baseline_clip(seed, threads, budget_s=30.0):
                        f"(batch 8 and batch 1 at {threads} threads, batch 1 at 1 thread) after warm-up; value = best of the {threads}-thread runs")
 
 
-def step_flops_per_cycle(nm, c_in=3, V=25):
-    """Algorithmic FLOPs of one 4-frame stride cycle of the ten continual blocks for nm skeletons (SURVEY 8d:
-    28.75 MMAC per skeleton-frame, frame-rate weighted): (gcn_flops, tcn_flops)."""
-    from continual_skeletons_amd.models import layer_table
-    rate, g, t = 4, 0, 0            # frames per 4-frame cycle entering the block
-    for (ci, co, s, res) in layer_table(c_in):
-        r = 4 if ci != co else 3
-        g += rate * r * ci * co * V
-        rate //= s
-        t += rate * (9 * co * co + (ci * co if (res and (ci != co or s != 1)) else 0)) * V
-    return 2 * g * nm, 2 * t * nm
-
-
 def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1, native_plan=True, fpl=4):
     """CoST-GCN online inference: `streams` concurrent streams per GPU, persistent ring-buffer state; one
     cycle = 4 consecutive frames (the stack's stride pattern) = one prediction per stream.  With shards > 1 the
@@ -444,7 +431,11 @@ def main():
         torch.cuda.empty_cache()
         _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1, native_plan=False)
         kcycles = 4
-        gfl, tfl = step_flops_per_cycle(args.streams * NTU["M"])
+        # the timed launches are the tcn_step_kernel launches of a cycle: blocks 5-10 (blocks 1-4, C_out = 64, advance with
+        # the fused csk_co_block_step_f32 launch, which does not go through the hook)
+        step_layers = [l for l in workmodel.step_layers(4) if l["co"] > 64]
+        tfl = 2.0 * args.streams * NTU["M"] * sum(l["tcn_macs"] for l in step_layers)
+        assert sn == kcycles * len(step_layers), (sn, len(step_layers))
         fps = args.frames_per_launch * args.streams * world * args.step_cycles / sdt
         ach = tfl * kcycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0
         straffic = load_traffic("traffic_tcn_step.json")
@@ -466,10 +457,11 @@ def main():
                      "roofline": {"bound": "mfma", "kernel": "tcn_step_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,
                                   "avg_launch_ms": round(stcn_ms / max(1, sn), 4),
-                                  "flops_per_launch": tfl / 10.0,
+                                  "flops_per_launch": tfl / len(step_layers),
                                   "timing": "single stream shard, launches driven from Python with HIP events around every "
-                                            "tcn_step launch of 4 cycles of 4 frames (same launch shape as tools/online_pass.py "
-                                            "--shards 1, whose rocprofv3 per-layer table is profiles/*_online_1shard.md)",
+                                            "tcn_step_kernel launch (blocks 5-10; blocks 1-4 use the fused block kernel) of 4 cycles of "
+                                            "4 frames: the launch shape of tools/online_pass.py --shards 1, whose rocprofv3 per-layer "
+                                            "table is profiles/r02_online_1shard.md (rows L5-L10 tcn_step)",
                                   "traffic": straffic["hbm_bytes_per_launch"] if straffic and straffic.get("streams") == args.streams else None,
                                   "traffic_source": (f"{straffic.get('source')} (committed PMC passes, not collected by this run)")
                                   if straffic and straffic.get("streams") == args.streams else None},

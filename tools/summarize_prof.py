@@ -23,8 +23,8 @@ def rows_of(pattern):
 
 
 def short(name):
-    for k in ("tcn_stage_kernel", "gcn_stage_kernel", "tcn_step_kernel", "input_norm_kernel", "pool_kernel", "fc_kernel",
-              "co_spatial_pool_kernel", "co_window_mean_kernel"):
+    for k in ("tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_step_kernel",
+              "co_block_kernel", "input_norm_kernel", "co_spatial_pool_kernel", "co_window_mean_kernel", "pool_kernel", "fc_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
             return k + t
@@ -42,7 +42,7 @@ def main(tag):
         agg[k][0] += 1
         agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     tot = sum(v[1] for v in agg.values())
-    lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag}): python bench.py --steps 3 --warmup 1 --step-cycles 8",
+    lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag}): python bench.py --steps 3 --warmup 1 --step-cycles 8 --no-cpu-baseline",
              "", "| kernel | calls | total ms | avg ms | % |", "|---|---|---|---|---|"]
     for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         lines.append(f"| {k} | {n} | {ms:.3f} | {ms / n:.4f} | {100 * ms / tot:.1f} |")
@@ -91,7 +91,7 @@ def main(tag):
         lines += ["", "## HBM traffic per launch, online workload (PMC passes of `tools/step_traffic_pass.py`: 4-frame launches over all 1024 streams = the launch shape of the kernel-timing pass)", "",
                   "| kernel | launches | FETCH_SIZE raw avg KiB | WRITE_SIZE raw avg KiB | HBM read MB (calibrated) | HBM write MB |", "|---|---|---|---|---|---|"]
         for k in sorted(set(fetch_s) | set(write_s)):
-            if "step_kernel" not in k and "gcn_stage" not in k:
+            if "step_kernel" not in k and "gcn_stage" not in k and "co_block" not in k:
                 continue
             f, w = fetch_s.get(k, []), write_s.get(k, [])
             fa = sum(f) / len(f) if f else 0.0
@@ -112,7 +112,7 @@ def main(tag):
     allsq = dict(sq)
     allsq.update({"step:" + k: v for k, v in sq_step.items()})
     for k, c in allsq.items():
-        if "stage" not in k and "step_kernel" not in k:
+        if "stage" not in k and "step_kernel" not in k and "co_block" not in k:
             continue
         g = sum(c["GRBM_GUI_ACTIVE"]) / 8
         if g == 0:
@@ -128,7 +128,7 @@ def main(tag):
         n = sum(v["launches"] for v in dom)
         hb = sum((v["read_MB"] + v["write_MB"]) * 1e6 * v["launches"] for v in dom) / n
         json.dump({"kernel": "tcn_stage_kernel", "hbm_bytes_per_launch": hb, "launches": n, "source": f"profiles/{tag}_traffic.json",
-                   "batch": 256}, open(os.path.join(ROOT, "profiles", "traffic_tcn_stage.json"), "w"), indent=1)
+                   "batch": 256, "summary": f"profiles/{tag}_rocprof_summary.md"}, open(os.path.join(ROOT, "profiles", "traffic_tcn_stage.json"), "w"), indent=1)
     dom = [v for k, v in step_traffic.items() if k.startswith("tcn_step_kernel")]
     if dom:
         n = sum(v["launches"] for v in dom)
