@@ -215,18 +215,30 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
                                   ksplit=self._pick_ksplit(p))
         return self._state
 
+    force_split_k = 0   # n > 1: split-K in every launch of this block, whatever its size (measurement only)
     split_k = 0     # 0: no split-K; n > 1: latency mode -- up to n channel ranges per tile when a launch is too small
 
+    THROUGHPUT_SPLIT_K = 3   # split-K of the 256-channel blocks (see _pick_ksplit)
+
     def _pick_ksplit(self, p: int) -> int:
-        """Split-K factor of the TCN step for a slab of p positions: only when the launch would otherwise hold fewer
-        than 64 workgroups (a handful of streams), at least two 8-channel chunks per split."""
+        """Split-K factor of this block's TCN step (csk_tcn_step_f32 ``ksplit``).
+        * Blocks with C_out >= 256 always cut their 2304-deep K loop into 3 channel ranges: their tiles are the longest
+          of the stack (128 x 128 x 2304) and come 400-800 per launch for 512 resident slots; three times as many tiles a
+          third as long pack the GPU better (measured at 1024 streams, two shards, 4 frames per launch: 954 k -> 966 k /
+          980 k / 965 k frames/s for 2 / 3 / 4 splits; splitting the 128-channel blocks as well: 944 k).  The factor does
+          NOT depend on the slab size, so a stream's results do not depend on how many streams share the slab.
+        * Latency mode (``split_k`` > 1, a handful of streams): up to ``split_k`` ranges when the launch would otherwise
+          hold fewer than 64 workgroups, at least two 8-channel chunks per split."""
+        if self.force_split_k > 1:                 # experiment switch (tools/online_pass.py --force-ksplit)
+            return self.force_split_k
+        base = self.THROUGHPUT_SPLIT_K if self.out_channels >= 256 else 1
         if self.split_k <= 1:
-            return 1
+            return base
         mt = 128 if self.out_channels % 128 == 0 else 64
         tiles = -(-p // (16384 // mt)) * (-(-self.out_channels // mt))
         if tiles >= 64:
-            return 1
-        return max(1, min(self.split_k, 16, (-(-self.out_channels // 8)) // 2))
+            return base
+        return max(base, min(self.split_k, 16, (-(-self.out_channels // 8)) // 2))
 
     def clean_state(self):
         if self._state is not None:

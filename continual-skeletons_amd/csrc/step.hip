@@ -84,7 +84,8 @@ struct StepParams {
     int res_mode, Cres, CresPad, relu;
     int xres_slots, xres_slot0, xres_step, out_slots, out_slot0;
     int fast_epi;      // P fits the 32-bit lane byte offsets of the scalar-base epilogue addressing
-    int ksplit, cper;  // split-K (latency mode): grid.z = emissions * ksplit, split ks covers channels [ks*cper, ..+cper)
+    unsigned gx, gy, gz;   // position tiles, m-tiles, emission groups [* ksplit] of the launch (the grid is 1-D)
+    int ksplit, cper;  // split-K (latency mode): emission groups * ksplit slices, split ks covers channels [ks*cper, ..+cper)
     float *part;       // and writes raw partial sums to part[(emission*ksplit + ks)][Cout][P]; 1 = off
     int64_t P;
 };
@@ -291,7 +292,12 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
 template <int MT, int E, int HS, bool SPLIT>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    tcn_step_tile<MT, E, HS, SPLIT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+    // XCD-aware work-item order (mfma_core.h): every XCD walks a contiguous range of items; m-tile fastest, then emission
+    // group, then position tile -- the m-tiles of a position tile read the SAME ring window (and emission groups at the
+    // same positions all but a few slots of it); with a plain (x, y, z) grid they sat gridDim.x dispatches apart, by when
+    // the window had left the 4 MB L2 (C = 256 launches fetched 966 MB for 525 MB of operands)
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    tcn_step_tile<MT, E, HS, SPLIT>(p, (int)(wid / (p.gy * p.gz)), (int)(wid % p.gy), (int)((wid / p.gy) % p.gz), smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,20 +623,24 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     // per emission (a wave's 64 columns must belong to one emission); stride-2 launches only as 128-row tiles of two
     // emissions (the only stride-2 shapes of the ST-GCN stack); split-K and the E = 1 form use the plain tile.
     int E = 1;
-    if (p.ksplit == 1 && k == 9 && !csk_diag_flag("CSK_STEP_NOFOLD")) {
-        if (!big && head_step == 1) E = (n_emit % 4 == 0) ? 4 : (n_emit % 2 == 0) ? 2 : 1;
-        if (big && head_step <= 2 && head_step >= 1) E = (n_emit % 2 == 0) ? 2 : 1;
+    if (k == 9 && !csk_diag_flag("CSK_STEP_NOFOLD")) {
+        if (!big && head_step == 1 && p.ksplit == 1) E = (n_emit % 4 == 0) ? 4 : (n_emit % 2 == 0) ? 2 : 1;
+        if (big && head_step <= 2 && head_step >= 1) E = (n_emit % 2 == 0) ? 2 : 1;      // also with split-K
     }
     const int NP = NT / E;
     void (*kern)(StepParams);
     size_t stage_floats;
 #define CSK_PICK(MT_, E_, HS_, SP_) (kern = tcn_step_kernel<MT_, E_, HS_, SP_>, stage_floats = RingStage<16384 / MT_ / E_, 8 + (E_ - 1) * HS_ + 1>::LDS_FLOATS)
-    if (p.ksplit > 1) big ? CSK_PICK(128, 1, 1, true) : CSK_PICK(64, 1, 1, true);
-    else if (big) E == 2 ? (head_step == 2 ? CSK_PICK(128, 2, 2, false) : CSK_PICK(128, 2, 1, false)) : CSK_PICK(128, 1, 1, false);
+    if (p.ksplit > 1) {
+        if (big) E == 2 ? (head_step == 2 ? CSK_PICK(128, 2, 2, true) : CSK_PICK(128, 2, 1, true)) : CSK_PICK(128, 1, 1, true);
+        else CSK_PICK(64, 1, 1, true);
+    } else if (big) E == 2 ? (head_step == 2 ? CSK_PICK(128, 2, 2, false) : CSK_PICK(128, 2, 1, false)) : CSK_PICK(128, 1, 1, false);
     else E == 4 ? CSK_PICK(64, 4, 1, false) : E == 2 ? CSK_PICK(64, 2, 1, false) : CSK_PICK(64, 1, 1, false);
 #undef CSK_PICK
     const size_t lds = (size_t)(9 * KC * MT + stage_floats) * sizeof(float);
-    dim3 grid((unsigned)((P + NP - 1) / NP), p.Mpad / MT, (n_emit / E) * p.ksplit);
+    p.gx = (unsigned)((P + NP - 1) / NP); p.gy = (unsigned)(p.Mpad / MT); p.gz = (unsigned)((n_emit / E) * p.ksplit);
+    if ((int64_t)p.gx * p.gy * p.gz >= (1ll << 31)) CSK_FAIL("tcn_step: grid too large");
+    dim3 grid(p.gx * p.gy * p.gz);
     hipStream_t s = (hipStream_t)stream;
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, p);
@@ -674,7 +684,7 @@ extern "C" int csk_co_block_step_f32(const float *xin, int xin_slots, int xin_sl
     t.Cres = res_mode ? c_in : 1; t.CresPad = round_up(t.Cres, CSK_CPAD); t.relu = 1; t.P = P;
     t.fast_epi = P < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     t.xres_slots = xin_slots; t.xres_slot0 = x_res_slot0; t.xres_step = 1; t.out_slots = out_slots; t.out_slot0 = out_slot0;
-    t.ksplit = 1; t.cper = t.Cpad; t.part = nullptr;
+    t.ksplit = 1; t.cper = t.Cpad; t.part = nullptr; t.gx = (unsigned)((P + NP - 1) / NP); t.gy = 1; t.gz = 1;
     p.xin = xin; p.gw = gcn_w; p.gbias = gcn_bias; p.ell_src = ell_src; p.ell_val = ell_val;
     for (int i = 0; i < 3; ++i) p.ell_cnt[i] = ell_cnt[i];
     p.ell_w = ell_w; p.xin_slots = xin_slots; p.xin_slot0 = xin_slot0; p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD);

@@ -22,6 +22,8 @@ ap.add_argument("--cycles", type=int, default=24)
 ap.add_argument("--streams", type=int, default=1024)
 ap.add_argument("--warm-cycles", type=int, default=0, help="default: enough to fill the stack and the temporal pool")
 ap.add_argument("--no-fuse", action="store_true", help="two launches per block everywhere (no csk_co_block_step_f32)")
+ap.add_argument("--force-ksplit", type=int, default=0, help="split-K factor forced on blocks with C_out >= --ksplit-min-c (experiment)")
+ap.add_argument("--ksplit-min-c", type=int, default=256)
 args = ap.parse_args()
 
 pkg = _bootstrap.load()
@@ -33,6 +35,10 @@ dev = torch.device("cuda:0")
 def make():
     net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
     bench.randomise_(net, seed=0)
+    if args.force_ksplit > 1:
+        for blk in net.layers.values():
+            if blk.out_channels >= args.ksplit_min_c:
+                blk.force_split_k = args.force_ksplit
     if args.no_fuse:
         for blk in net.layers.values():
             blk.fuse_step = False
