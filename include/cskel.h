@@ -157,7 +157,8 @@ int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, i
 
 /*
  * Emitting step(s) of CoTemporalConvolution (+ residual + ReLU of CoSpatioTemporalBlock, base.py:412-446).
- * For emission j = 0 .. n_emit-1 (one grid.z slice each; n_emit > 1 batches the frames of a stride cycle):
+ * For emission j = 0 .. n_emit-1 (n_emit > 1 batches the frames of a stride cycle; the kernel folds 2 or 4 emissions
+ * into one workgroup tile when their count allows, so that one staged ring window serves all their taps):
  *     h_j   = (head + j*head_step) mod slots                       slot of the newest post-GCN frame
  *     out_j[co, p] = ReLU( sum_r sum_c W[r][c][co] * ring[(h_j-(k-1)+r) mod slots][c][p] + bias[co] + res_j[co, p] )
  *  ring   [slots][c][P] post-GCN frames; zero-initialised slots act as the clip conv's zero padding;
@@ -166,10 +167,12 @@ int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, i
  *         (x_res_slot0 + j*x_res_step) mod x_res_slots = the input delayed by (k-1)/2 frames (co.Delay).
  *  out    ring [out_slots][c_out][P]; emission j is written to slot (out_slot0 + j) mod out_slots.
  *  All ring bases 16-byte aligned, P % 4 == 0.
- *  ksplit > 1 (latency mode for few streams, where one workgroup per tile would walk the whole K loop alone): the
- *  channel axis is cut into up to ksplit ranges computed by separate workgroups into `partial`
+ *  ksplit > 1: the channel axis is cut into up to ksplit ranges computed by separate workgroups into `partial`
  *  ([n_emit * ksplit][c_out][P] floats, 16-byte aligned) and summed in a fixed order by a second kernel that also
- *  applies bias / identity residual / ReLU.  Results differ from ksplit = 1 by fp32 summation order only.
+ *  applies bias / identity residual / ReLU.  Used (a) by the 256-channel blocks always (ksplit = 3: three times as many
+ *  tiles a third as long fill the GPU better than 800 tiles of 295 k MFMA cycles) and (b) in latency mode for few
+ *  streams, where one workgroup per tile would walk the whole K loop alone.  Results differ from ksplit = 1 by fp32
+ *  summation order only; for a given ksplit they do not depend on n_emit or P.
  */
 int csk_tcn_step_f32(const float *ring, int slots, int head, int head_step, int n_emit, const float *w,
                      const float *x_res, int x_res_slots, int x_res_slot0, int x_res_step,
