@@ -159,3 +159,18 @@ def test_co_stack_matches_clip_stack():
 def test_co_stgcn_geometry_and_pool_defaults():
     assert o.co_stgcn_geometry() == (153, 76, 4)
     assert o.co_stgcn_pool_defaults(300) == (75, 19)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_committed_fixtures_verify_against_the_reference():
+    """tests/golden/make_golden.py --verify: every committed fixture regenerates bit-identically from the reference's
+    own classes, and every stored state_dict re-run on its stored input reproduces the stored output exactly (0.0).
+    Runs only where /root/reference exists (never on the GPU box); a subprocess, because the script installs import
+    stubs and shadows the `datasets` package."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
+    out = subprocess.run([sys.executable, script, "--verify"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "all committed fixtures verified against the reference: 0.0" in out.stdout
