@@ -3,6 +3,8 @@
 // Two kernels share GcnParams: gcn_stage_sparse_kernel (skeleton graphs: the aggregated B operand is formed on the
 // fly from register-resident adjacency entries) and gcn_stage_kernel (general: any / dense / per-sample / per-frame
 // adjacency, ELL tables in LDS, VALU aggregation into an LDS operand tile).  GEMM core: mfma_core.h.
+#include <type_traits>
+
 #include "mfma_core.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -24,6 +26,7 @@ struct GcnParams {
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup of the sparse kernel
     int fast_epi;        // channel strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
     int no_pair_reads;   // diagnostic (CSK_NO_PAIR_READS): general kernel aggregates with scalar LDS reads for even V too
+    int no_vec;          // diagnostic (CSK_GCN_NOVEC): sparse kernel stages activations element-wise on every tile
 };
 
 template <int MT, int NJ>
@@ -525,7 +528,6 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
     constexpr int WB = (R * KCG_ * M4 + NTHREADS - 1) / NTHREADS;   // f32x4 of weights per thread per chunk
     constexpr int RPW = KCG_ / (NTHREADS / 64);            // activation rows per wave per chunk
     constexpr int NJ = MT == 128 ? 3 : 5;                  // 64-lane sweeps per activation row (span <= 192 / 320)
-    constexpr int NL = WB + RPW * NJ;                      // staging loads per thread per chunk
     constexpr int NS = KCG_ / 2;                           // MFMA k-steps per chunk
     constexpr int NH = NS / 2;                             // ... of which the first NH carry the next-next chunk's loads
     static_assert(KCG_ % 8 == 0, "a chunk is a whole number of rows per wave");
@@ -583,7 +585,13 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
         wgo[u] = (unsigned)(((row / KCG_) * p.CinPad + (row % KCG_)) * p.Mpad + m4 * 4);
         wlo[u] = (unsigned)(e * 4);
     }
+    // Activation staging, two forms chosen per workgroup (uniform): element-wise (NJ sweeps of 64 lanes per row), or --
+    // when the row holds 4*ceil(span/4) positions from the tile's first frame on (every tile but the last of a
+    // segment) -- 16-byte loads (4-byte aligned in global memory, aligned in LDS) and ds_write_b128: a quarter of the
+    // load and LDS-write instructions.
+    constexpr int NJ4 = (NJ + 3) / 4;
     float bv[RPW][NJ];
+    f32x4 bv4[RPW][NJ4];
     unsigned bgo[NJ], blo[NJ];
 #pragma unroll
     for (int u = 0; u < NJ; ++u) {
@@ -591,28 +599,47 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
         bgo[u] = (unsigned)(ta * V + j);                   // always inside [0, Q): whole frames of this segment
         blo[u] = (unsigned)j;
     }
-    // staging load i of chunk c0 (i is a literal after unrolling): 0..WB-1 weights, then activation (row, sweep) pairs
-    auto issue_one = [&](int i, int c0) {
+    const int nvec = (span + 3) / 4;
+    const bool vec = ta * V + 4 * nvec <= Q && p.Cin >= KCG_ && !p.no_vec;     // uniform (a 3-channel input: nothing to gain)
+    unsigned bgo4[NJ4], blo4[NJ4];
+#pragma unroll
+    for (int u = 0; u < NJ4; ++u) {
+        const int i = min(u * 64 + lane, nvec - 1);
+        bgo4[u] = (unsigned)(ta * V + 4 * i);
+        blo4[u] = (unsigned)(4 * i);
+    }
+    // staging load i of chunk c0 (i is a literal after unrolling): 0..WB-1 weights, then activation (row, sweep) pairs.
+    // channels >= Cin: the row is CLAMPED, not zeroed -- the packed weights of padding channels are zero, so a finite
+    // duplicate contributes nothing (and a NaN / Inf duplicate only reaches outputs the real row already poisons); a
+    // select here would make the compiler wait for the load right behind its issue
+    auto issue_one = [&](auto vtag, int i, int c0) {
+        constexpr bool VEC = decltype(vtag)::value;
+        constexpr int NX = VEC ? NJ4 : NJ;
         if (i < WB) {
             wv[i] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)c0 * p.Mpad + wgo[i]);
         } else {
-            const int rr = (i - WB) / NJ, u = (i - WB) % NJ;
-            // channels >= Cin: the row is CLAMPED, not zeroed -- the packed weights of padding channels are zero, so a
-            // finite duplicate contributes nothing (and a NaN / Inf duplicate only reaches outputs the real row already
-            // poisons); a select here would make the compiler wait for the load right behind its issue
+            const int rr = (i - WB) / NX, u = (i - WB) % NX;
             const int c = min(c0 + wave + rr * (NTHREADS / 64), p.Cin - 1);
-            bv[rr][u] = (seg_base + (int64_t)c * p.x_chan_stride)[bgo[u]];
+            const float *row = seg_base + (int64_t)c * p.x_chan_stride;
+            if (VEC) bv4[rr][u] = *reinterpret_cast<const f32x4u *>(row + bgo4[u]);
+            else bv[rr][u] = row[bgo[u]];
         }
     };
-    auto commit = [&](float *buf) {
+    auto commit = [&](auto vtag, float *buf) {
+        constexpr bool VEC = decltype(vtag)::value;
         float *Wl = buf, *Bx = buf + wsz;
 #pragma unroll
         for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(Wl + wlo[u]) = wv[u];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             float *dst = Bx + (wave + rr * (NTHREADS / 64)) * p.ldb;
+            if (VEC) {
 #pragma unroll
-            for (int u = 0; u < NJ; ++u) dst[blo[u]] = bv[rr][u];
+                for (int u = 0; u < NJ4; ++u) *reinterpret_cast<f32x4 *>(dst + blo4[u]) = bv4[rr][u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NJ; ++u) dst[blo[u]] = bv[rr][u];
+            }
         }
     };
     const int offA = wm * 64 + l31;
@@ -646,39 +673,44 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
     };
 
     const int nchunks = p.CinPad / KCG_;                   // CinPad is a multiple of CSK_CPAD = 16
+    auto k_loop = [&](auto vtag) {
+        constexpr int NLX = WB + RPW * (decltype(vtag)::value ? NJ4 : NJ);     // staging loads per thread per chunk
 #pragma unroll
-    for (int i = 0; i < NL; ++i) issue_one(i, 0);
-    commit(smem);
-    if (nchunks > 1) {
+        for (int i = 0; i < NLX; ++i) issue_one(vtag, i, 0);
+        commit(vtag, smem);
+        if (nchunks > 1) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) issue_one(i, KCG_);
-    }
-    __syncthreads();
-    for (int c = 0; c + 1 < nchunks; ++c) {
-        float *cur = smem + (c & 1) * bufsz, *oth = smem + ((c & 1) ^ 1) * bufsz;
-        commit(oth);                                       // chunk c+1: registers -> the other buffer
-        // chunk c+2's loads; past the end the last chunk is re-loaded into the (then dead) staging registers, so that
-        // the k-step sequence below stays ONE basic block (a uniform branch per load group would confine the
-        // scheduler's LDS-read / MFMA interleave to single k-steps)
-        const int cnext = min(c + 2, nchunks - 1) * KCG_;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            // all loads go out in the FIRST half of the k-steps: the second half (and the barrier) is their latency
-            // cover before the commit at the top of the next iteration
-            if (s < NH) {
-#pragma unroll
-                for (int i = s * NL / NH; i < (s + 1) * NL / NH; ++i) issue_one(i, cnext);
-                // pin the loads to this k-step: left alone, the machine scheduler sinks all of them to the end of the
-                // block, right in front of the barrier and the commit that needs them (a mask that only holds back
-                // vector-memory instructions does not help: the MFMAs are then hoisted over the loads instead)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mfma_step(cur, s);
+            for (int i = 0; i < NLX; ++i) issue_one(vtag, i, KCG_);
         }
-        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
-    }
+        for (int c = 0; c + 1 < nchunks; ++c) {
+            float *cur = smem + (c & 1) * bufsz, *oth = smem + ((c & 1) ^ 1) * bufsz;
+            commit(vtag, oth);                                 // chunk c+1: registers -> the other buffer
+            // chunk c+2's loads; past the end the last chunk is re-loaded into the (then dead) staging registers, so that
+            // the k-step sequence below stays ONE basic block (a uniform branch per load group would confine the
+            // scheduler's LDS-read / MFMA interleave to single k-steps)
+            const int cnext = min(c + 2, nchunks - 1) * KCG_;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                // all loads go out in the FIRST half of the k-steps: the second half (and the barrier) is their latency
+                // cover before the commit at the top of the next iteration
+                if (s < NH) {
+#pragma unroll
+                    for (int i = s * NLX / NH; i < (s + 1) * NLX / NH; ++i) issue_one(vtag, i, cnext);
+                    // pin the loads to this k-step: left alone, the machine scheduler sinks all of them to the end of the
+                    // block, right in front of the barrier and the commit that needs them (a mask that only holds back
+                    // vector-memory instructions does not help: the MFMAs are then hoisted over the loads instead)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma_step(cur, s);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+        }
+    };
+    if (vec) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     const float *last = smem + ((nchunks - 1) & 1) * bufsz;
     // Epilogue operands: loaded after the K loop, one 32-row half at a time (register budget of three workgroups / CU)
     const int rbase = m0 + wm * 64;
@@ -783,6 +815,7 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     p.adj_per_frame = adj_per_frame != 0;
     p.stamps = csk_diag_stamps();
     p.no_pair_reads = csk_diag_flag("CSK_NO_PAIR_READS");
+    p.no_vec = csk_diag_flag("CSK_GCN_NOVEC");
     // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
     p.fast_epi = x_chan_stride < (1ll << 27) && y_chan_stride < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     if (p.adj_per_frame && !p.dense) CSK_FAIL("gcn_stage: per-frame adjacency must be dense (ell_w == V, ell_cnt == V)");

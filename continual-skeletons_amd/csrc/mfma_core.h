@@ -168,12 +168,71 @@ struct BStage {
             }
         }
     }
+    // third G of the next chunk's loads: sweeps 3G .. 3G+2 (plus 3G+9 .. for long spans)
+    template <int G>
+    __device__ __forceinline__ void issue_third(const float *__restrict__ seg_base, int C, int64_t chan_stride, int c0,
+                                                int wave) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            issue_slot(3 * G + j, seg_base, C, chan_stride, c0, wave);
+            if (NJ > 9) issue_slot(3 * G + j + 9, seg_base, C, chan_stride, c0, wave);
+        }
+    }
     __device__ __forceinline__ void commit(float *__restrict__ Bl, int ldb, int wave) const {
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             float *dst = Bl + (wave + rr * (NTHREADS / 64)) * ldb;
 #pragma unroll
             for (int u = 0; u < NJ; ++u) dst[loff[u]] = v[rr][u];
+        }
+    }
+};
+
+// Vector form of BStage for tiles whose whole staged span lies inside the activation row (no conv zero padding to
+// apply): 16-byte global loads (4-byte aligned -- rows and tap shifts are not 16-byte aligned in general; the LDS side is)
+// and ds_write_b128, i.e. a quarter of the load and LDS-write instructions of the scalar form.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int NJ4>
+struct BStage4 {
+    static constexpr int RPW = KC / (NTHREADS / 64);   // rows per wave
+    unsigned goff[NJ4];   // first position of the vector inside a channel row
+    unsigned loff[NJ4];   // ... inside an LDS row
+    f32x4 v[RPW][NJ4];
+    __device__ __forceinline__ void setup(int pbase, int span, int lane) {
+        const int nvec = (span + 3) / 4;
+#pragma unroll
+        for (int u = 0; u < NJ4; ++u) {
+            const int i = min(u * 64 + lane, nvec - 1);
+            goff[u] = (unsigned)(pbase + 4 * i);
+            loff[u] = (unsigned)(4 * i);
+        }
+    }
+    __device__ __forceinline__ void issue_slot(int u, const float *__restrict__ seg_base, int C, int64_t chan_stride,
+                                               int c0, int wave) {
+        if (u >= NJ4) return;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int c = min(c0 + wave + rr * (NTHREADS / 64), C - 1);     // clamped: padding channels carry zero weights
+            v[rr][u] = *reinterpret_cast<const f32x4u *>(seg_base + (int64_t)c * chan_stride + goff[u]);
+        }
+    }
+    __device__ __forceinline__ void issue(const float *__restrict__ seg_base, int C, int64_t chan_stride, int c0, int wave) {
+#pragma unroll
+        for (int u = 0; u < NJ4; ++u) issue_slot(u, seg_base, C, chan_stride, c0, wave);
+    }
+    // third G of the next chunk's loads: sweep G (and sweep 3 with the first third)
+    template <int G>
+    __device__ __forceinline__ void issue_third(const float *__restrict__ seg_base, int C, int64_t chan_stride, int c0,
+                                                int wave) {
+        issue_slot(G, seg_base, C, chan_stride, c0, wave);
+        if (G == 0) issue_slot(3, seg_base, C, chan_stride, c0, wave);
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Bl, int ldb, int wave) const {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            float *dst = Bl + (wave + rr * (NTHREADS / 64)) * ldb;
+#pragma unroll
+            for (int u = 0; u < NJ4; ++u) *reinterpret_cast<f32x4 *>(dst + loff[u]) = v[rr][u];
         }
     }
 };
@@ -204,16 +263,3 @@ __device__ __forceinline__ void mfma_taps(const float *__restrict__ Wl, const fl
     }
 }
 
-// one third (slots 3G .. 3G+2, plus 3G+9 .. for long spans) of the next chunk's staging loads; G is a template
-// constant so that every register-array index is a literal when the arrays are scalarised
-template <int G, int MT, int NJ>
-__device__ __forceinline__ void issue_third(WStage<MT> &ws, BStage<NJ> &bs, const float *__restrict__ wnext,
-                                            const float *__restrict__ seg_base, int C, int64_t chan_stride, int cnext,
-                                            int wave) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        ws.issue_slot(3 * G + j, wnext);
-        bs.issue_slot(3 * G + j, seg_base, C, chan_stride, cnext, wave);
-        if (NJ > 9) bs.issue_slot(3 * G + j + 9, seg_base, C, chan_stride, cnext, wave);
-    }
-}

@@ -29,6 +29,7 @@ struct TcnParams {
     int nt;                       // positions per tile actually used (<= 16384 / MT)
     int fast_epi;                 // row strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
     int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
+    int vec_stage;                // 16-byte activation staging on interior tiles (diagnostic CSK_TCN_NOVEC=1 turns it off)
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
 
@@ -121,7 +122,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         }
     };
     const bool conv_res = p.res_mode == CSK_RES_CONV;
-    // ---- phase 1: k x 1 temporal conv over y
+    // ---- phase 1: k x 1 temporal conv over y.  The loop is written once over the activation-staging type: tiles whose
+    // whole staged span lies inside the row (no zero padding to apply: all but the 1-2 tiles at either end of a
+    // sequence) stage with 16-byte loads / LDS writes (BStage4), the others element-wise with clamp + select (BStage).
     {
         const int fa = p.stride * ta - p.pad;
         const int span = (p.stride * (tb - ta) + p.K) * V;
@@ -129,50 +132,66 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         const int64_t cs = (int64_t)p.Tin * V;
         const float *wbase = p.w + m0;
         ws.setup(p.K, p.Cpad, p.Mpad, tid);
-        bs.setup(fa * V, span, p.Tin * V, lane);
-        ws.issue(wbase);
-        bs.issue(seg_base, p.C, cs, 0, wave);
-        int c0 = 0;
-        unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;   // diagnostic phase sums (p.stamps only)
-        for (; c0 + KC < p.Cpad; c0 += KC) {
-            if (p.stamps) tq = __builtin_amdgcn_s_memtime();
-            __syncthreads();                       // previous chunk's LDS reads are done
-            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
-            ws.commit(Wl);
-            bs.commit(Bl, p.ldb, wave);
-            __syncthreads();
-            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
-            if (p.stamps && c0 == 0) st1 = __builtin_amdgcn_s_memtime();
-            {
-                // the next chunk's loads are issued in three bursts of 9 between three tap segments (see mfma_taps)
-                const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
-                const int cn = c0 + KC, t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
-                if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
-                issue_third<0>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
-                // raised priority while in an MFMA segment: this wave then wins issue arbitration against the
-                // SIMD partner's commit / load-issue phase (+2 % measured)
-                if (p.prio) __builtin_amdgcn_s_setprio(1);
-                mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
-                __builtin_amdgcn_s_setprio(0);
-                issue_third<1>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
-                if (p.prio) __builtin_amdgcn_s_setprio(1);
-                if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
-                __builtin_amdgcn_s_setprio(0);
-                issue_third<2>(ws, bs, wnext, seg_base, p.C, cs, cn, wave);
-                if (p.prio) __builtin_amdgcn_s_setprio(1);
-                if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
-                __builtin_amdgcn_s_setprio(0);
+        auto phase1 = [&](auto &bx) {
+            ws.issue(wbase);
+            bx.issue(seg_base, p.C, cs, 0, wave);
+            int c0 = 0;
+            unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;   // diagnostic phase sums (p.stamps only)
+            for (; c0 + KC < p.Cpad; c0 += KC) {
+                if (p.stamps) tq = __builtin_amdgcn_s_memtime();
+                __syncthreads();                       // previous chunk's LDS reads are done
+                if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
+                ws.commit(Wl);
+                bx.commit(Bl, p.ldb, wave);
+                __syncthreads();
+                if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
+                if (p.stamps && c0 == 0) st1 = __builtin_amdgcn_s_memtime();
+                {
+                    // the next chunk's loads are issued in three bursts between three tap segments (see mfma_taps)
+                    const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
+                    const int cn = c0 + KC, t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
+                    if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
+                    bx.template issue_third<0>(seg_base, p.C, cs, cn, wave);
+                    // raised priority while in an MFMA segment: this wave then wins issue arbitration against the
+                    // SIMD partner's commit / load-issue phase (+2 % measured)
+                    if (p.prio) __builtin_amdgcn_s_setprio(1);
+                    mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                    for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
+                    bx.template issue_third<1>(seg_base, p.C, cs, cn, wave);
+                    if (p.prio) __builtin_amdgcn_s_setprio(1);
+                    if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                    for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
+                    bx.template issue_third<2>(seg_base, p.C, cs, cn, wave);
+                    if (p.prio) __builtin_amdgcn_s_setprio(1);
+                    if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph3 += t - tq; tq = t; }
             }
-            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph3 += t - tq; tq = t; }
+            if (p.stamps && lane == 0) {
+                unsigned long long *o = p.stamps + (size_t)gridDim.x * 6 + ((size_t)blockIdx.x * 4 + wave) * 4;
+                o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3;
+            }
+            __syncthreads();                           // peeled last chunk
+            ws.commit(Wl);
+            bx.commit(Bl, p.ldb, wave);
+            __syncthreads();
+        };
+        const bool interior = p.vec_stage && fa >= 0 && fa * V + 4 * ((span + 3) / 4) <= p.Tin * V;     // uniform
+        if (interior) {
+            BStage4<(NJ + 3) / 4> b4;
+            b4.setup(fa * V, span, lane);
+            phase1(b4);
+        } else {
+            bs.setup(fa * V, span, p.Tin * V, lane);
+            phase1(bs);
         }
-        if (p.stamps && lane == 0) {
-            unsigned long long *o = p.stamps + (size_t)gridDim.x * 6 + ((size_t)blockIdx.x * 4 + wave) * 4;
-            o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3;
-        }
-        __syncthreads();                           // peeled last chunk
-        ws.commit(Wl);
-        bs.commit(Bl, p.ldb, wave);
-        __syncthreads();
         if (!conv_res && OCC == 2) { load_half(0); load_half(1); }
         mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
     }
@@ -286,6 +305,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
     p.stamps = csk_diag_stamps();
     p.prio = !csk_diag_flag("CSK_NOPRIO");
+    p.vec_stage = !csk_diag_flag("CSK_TCN_NOVEC");
     // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
     p.fast_epi = (int64_t)p.Tres * V < (1ll << 27) && (int64_t)t_out * V < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     const bool big = (p.Mpad % 128) == 0;
