@@ -220,3 +220,22 @@ def test_fusion_file_loaders(tmp_path):
         fusion.load_preds(tmp_path / "p.txt")
     with pytest.raises(FileNotFoundError):
         fusion.load_preds(tmp_path / "missing.npy")
+
+
+def test_co_block_step_argument_errors_are_reported_without_a_gpu():
+    """csk_co_block_step_f32 validates its arguments before it touches the device: bad geometry comes back as a
+    negative return code with a message (no launch, so this runs on the CPU-only container)."""
+    import ctypes as C
+    lib = pkg.native.lib()
+    fake = C.c_void_p(0x1000)                    # non-null, 16-byte aligned; never dereferenced on these paths
+    cnt = (C.c_int32 * 3)(1, 1, 4)
+
+    def call(c_in=64, c_out=64, y_slots=16, V=25, P=200, n_skel=8, res_mode=1, gcn_res=1, cnt_=cnt):
+        return lib.csk_co_block_step_f32(fake, 16, 0, c_in, fake, fake, fake, fake, C.cast(cnt_, C.c_void_p), 4, gcn_res,
+                                         fake, y_slots, 0, fake, fake, res_mode, 12, fake, 16, 0, c_out, n_skel, V, P, None)
+
+    for kwargs, needle in [(dict(c_out=128), "c_out <= 64"), (dict(y_slots=9), "too shallow"), (dict(P=202), "multiple of 4"),
+                           (dict(c_in=32), "identity gcn residual"), (dict(res_mode=2), "none or identity"),
+                           (dict(cnt_=(C.c_int32 * 3)(2, 1, 4)), "skeleton-sparse"), (dict(V=43, P=344), "longer than 128")]:
+        assert call(**kwargs) < 0
+        assert needle in lib.csk_last_error().decode(), (kwargs, lib.csk_last_error().decode())
