@@ -215,7 +215,6 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
                                   ksplit=self._pick_ksplit(p))
         return self._state
 
-    force_split_k = 0   # n > 1: split-K in every launch of this block, whatever its size (measurement only)
     split_k = 0     # 0: no split-K; n > 1: latency mode -- up to n channel ranges per tile when a launch is too small
 
     THROUGHPUT_SPLIT_K = 3   # split-K of the 256-channel blocks (see _pick_ksplit)
@@ -229,8 +228,6 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
           NOT depend on the slab size, so a stream's results do not depend on how many streams share the slab.
         * Latency mode (``split_k`` > 1, a handful of streams): up to ``split_k`` ranges when the launch would otherwise
           hold fewer than 64 workgroups, at least two 8-channel chunks per split."""
-        if self.force_split_k > 1:                 # experiment switch (tools/online_pass.py --force-ksplit)
-            return self.force_split_k
         base = self.THROUGHPUT_SPLIT_K if self.out_channels >= 256 else 1
         if self.split_k <= 1:
             return base

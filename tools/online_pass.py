@@ -38,7 +38,7 @@ def make():
     if args.force_ksplit > 1:
         for blk in net.layers.values():
             if blk.out_channels >= args.ksplit_min_c:
-                blk.force_split_k = args.force_ksplit
+                blk._pick_ksplit = lambda p, k=args.force_ksplit: k      # measurement only: overrides the block's policy
     if args.no_fuse:
         for blk in net.layers.values():
             blk.fuse_step = False
