@@ -33,19 +33,21 @@ import workmodel  # noqa: E402  (tools/workmodel.py: SURVEY 8d work accounting, 
 
 PEAK_F32_MFMA_TFLOPS = workmodel.PEAK_F32_MFMA_TFLOPS     # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32)
 NTU = dict(C=3, T=300, V=25, M=2, classes=60)
+KIN_SHAPE = (3, 300, 18, 2)        # Kinetics-400 skeleton shape (C, T, V, M), BASELINE.json configs[3]
 
 
-def randomise_(net, seed):
+def randomise_(net, seed, attn_scale=1.0):
     """Random-init weights of the named architecture with non-trivial BN statistics (data: synthetic).  EVERY parameter
     and buffer is drawn from the seeded generator (the constructors' own kaiming / normal inits use the unseeded global
-    RNG and would differ from rank to rank and from instance to instance)."""
+    RNG and would differ from rank to rank and from instance to instance).  ``attn_scale``: graph_attn scale -- 1 for
+    ST-GCN (multiplicative mask, base.py:262), ~1/V for A-GCN where it is an additive dense matrix (a_gcn.py:50)."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, prm in net.named_parameters():
             if name.endswith(".A") or name == "A":
                 continue                                                   # the graph's adjacency
             if name.endswith("graph_attn"):
-                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+                prm.copy_((torch.rand(prm.shape, generator=g) + 0.5) * attn_scale)
             elif "bn" in name and name.endswith("weight"):
                 prm.copy_(torch.rand(prm.shape, generator=g) * 0.5 + 0.25)
             elif name.endswith("bias"):
@@ -135,36 +137,44 @@ def _median_rate(fn, units, runs=5, warm=2, budget_s=10.0):
     return units / statistics.median(ts), len(ts)
 
 
-def cpu_baseline_clip(seed, threads, budget_s=30.0):
+def cpu_baseline_clip(seed, threads, budget_s=30.0, adaptive=False):
     """Oracle (CPU port of the reference op sequence) per the reference's own protocol (scripts/benchmark_all_ntu60.py:
     15-18,52: batch 1; plus batch 8): median of 5 after 2 warm-ups, at `threads` threads and (batch 1) at one thread,
-    each leg inside its share of the time budget."""
+    each leg inside its share of the time budget.  adaptive: A-GCN at the Kinetics-400 shape (configs[3])."""
     from oracle import stgcn_oracle as o
     import _bootstrap
     pkg = _bootstrap.load()
-    net = pkg.StGcn(pkg.ntu_graph().A).eval()
-    randomise_(net, seed)
+    if adaptive:
+        net = pkg.AGcn(pkg.kinetics_graph().A, KIN_SHAPE, 400).eval()
+        randomise_(net, seed, attn_scale=1 / 18)
+        shape, fwd, what = KIN_SHAPE, (lambda xx, sd: o.stgcn_forward(xx, sd, gcn=o.adaptive_graph_conv)), "A-GCN, Kinetics-400-shape clips"
+    else:
+        net = pkg.StGcn(pkg.ntu_graph().A).eval()
+        randomise_(net, seed)
+        shape, fwd, what = (NTU["C"], NTU["T"], NTU["V"], NTU["M"]), o.stgcn_forward, "NTU-60 clips"
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    x = torch.rand((8, NTU["C"], NTU["T"], NTU["V"], NTU["M"]), generator=torch.Generator().manual_seed(1))
+    x = torch.rand((8,) + tuple(shape), generator=torch.Generator().manual_seed(1))
     runs = {}
     with torch.no_grad():
         torch.set_num_threads(threads)
-        runs["batch8"], n8 = _median_rate(lambda: o.stgcn_forward(x, sd), 8, budget_s=0.4 * budget_s)
-        runs["batch1"], n1 = _median_rate(lambda: o.stgcn_forward(x[:1], sd), 1, budget_s=0.2 * budget_s)
+        runs["batch8"], n8 = _median_rate(lambda: fwd(x, sd), 8, budget_s=0.4 * budget_s)
+        runs["batch1"], n1 = _median_rate(lambda: fwd(x[:1], sd), 1, budget_s=0.2 * budget_s)
         torch.set_num_threads(1)
-        runs["batch1_one_thread"], n1t = _median_rate(lambda: o.stgcn_forward(x[:1], sd), 1, runs=3, warm=1, budget_s=0.4 * budget_s)
+        runs["batch1_one_thread"], n1t = _median_rate(lambda: fwd(x[:1], sd), 1, runs=3, warm=1, budget_s=0.4 * budget_s)
         torch.set_num_threads(threads)
     best = max(runs["batch8"], runs["batch1"])
     return dict(value=round(best, 3), unit="clips/s", cores=threads, kind="port",
                 runs={k: round(v, 3) for k, v in runs.items()},
-                sample=f"oracle.stgcn_forward, torch CPU fp32, NTU-60 clips; median of {n8} / {n1} / {n1t} timed passes "
+                sample=f"oracle.stgcn_forward, torch CPU fp32, {what}; median of {n8} / {n1} / {n1t} timed passes "
                        f"(batch 8 and batch 1 at {threads} threads, batch 1 at 1 thread) after warm-up; value = best of the {threads}-thread runs")
 
 
-def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1, native_plan=True, fpl=4):
+def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, parallel, dist, shards=1, native_plan=True, fpl=4, use_dist=None):
     """CoST-GCN online inference: `streams` concurrent streams per GPU, persistent ring-buffer state; one
     cycle = 4 consecutive frames (the stack's stride pattern) = one prediction per stream.  With shards > 1 the
     stream axis is split into independent shards advanced on separate HIP streams (parallel.StreamShards)."""
+    use_dist = world > 1 if use_dist is None else use_dist
+
     def make():
         net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
         net.use_native_plan = native_plan     # False: launches are driven from Python so that they can be timed one by one
@@ -181,19 +191,19 @@ def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, paral
         nonlocal fi
         out = eng.forward_cycle([frames[(fi + f) % 8] for f in range(fpl)])   # fpl frames, one launch pair per block
         fi += fpl
-        return parallel.all_gather_logits(out) if (world > 1 and out is not None) else out
+        return parallel.all_gather_logits(out) if (use_dist and out is not None) else out
 
     with LaunchTimer(pkg, "tcn_step_launch") as lt:
         for _ in range(warm_cycles):
             out = cycle()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         lt.enabled = shards == 1            # per-launch events are only meaningful without concurrent shards
         t0 = time.perf_counter()
         for _ in range(cycles):
             out = cycle()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -203,24 +213,33 @@ def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, paral
     return dt, tcn_ms, n_launch, eng.state_bytes()
 
 
-def cpu_baseline_step(seed, threads, budget_s=20.0):
+def cpu_baseline_step(seed, threads, budget_s=20.0, adaptive=False):
     """Oracle continual path (port of the reference op sequence + restated continual protocol), one stream (batch 1, the
     reference's protocol): 76 warm-up frames (models/base.py:144-159), then the median rate of up to 5 segments of
-    steady-state frames (100 each when the time budget allows) -- at `threads` threads and at one thread."""
+    steady-state frames (100 each when the time budget allows) -- at `threads` threads and at one thread.
+    adaptive: CoAGCN (per-frame attention) at the Kinetics-400 shape (configs[3])."""
     from oracle import stgcn_oracle as o
     import _bootstrap
     import statistics
     pkg = _bootstrap.load()
-    net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
-    randomise_(net, seed)
-    sd = {k: v.clone() for k, v in pkg.StGcn(pkg.ntu_graph().A).state_dict().items()}
-    sd.update({k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in net.state_dict().items()})
-    x = torch.rand((1, NTU["C"], 200, NTU["V"], NTU["M"]), generator=torch.Generator().manual_seed(2))
+    if adaptive:
+        net = pkg.CoAGcn(pkg.kinetics_graph().A, KIN_SHAPE, 400).eval()
+        randomise_(net, seed, attn_scale=1 / 18)
+        shape, what = KIN_SHAPE, "CoAGCN, one Kinetics-400-shape stream"
+    else:
+        net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+        randomise_(net, seed)
+        shape, what = (NTU["C"], NTU["T"], NTU["V"], NTU["M"]), "one NTU-60 stream"
+    sd = {k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in net.state_dict().items()}
+    x = torch.rand((1, shape[0], 200, shape[2], shape[3]), generator=torch.Generator().manual_seed(2))
     info = {}
 
     def rate(tag, nthreads, budget):
         torch.set_num_threads(nthreads)
         orc = o.CoStGcnOracle(sd)
+        if adaptive:
+            for b in orc.blocks:
+                b.gcn = o.adaptive_graph_conv
         rates = []
         with torch.no_grad():
             t0 = time.perf_counter()
@@ -245,50 +264,67 @@ def cpu_baseline_step(seed, threads, budget_s=20.0):
     best = max(runs, key=runs.get)          # tiny per-frame ops: one thread can beat the thread pool
     return dict(value=round(runs[best], 2), unit="frames/s", cores=threads if best == "all_threads" else 1, kind="port",
                 runs={k: round(v, 2) for k, v in runs.items()},
-                sample=f"oracle.CoStGcnOracle, one NTU-60 stream: 76 warm-up frames, then median of {info['all_threads'][0]} segments "
+                sample=f"oracle.CoStGcnOracle, {what}: 76 warm-up frames, then median of {info['all_threads'][0]} segments "
                        f"of {info['all_threads'][1]} steady-state frames at {threads} threads ({info['one_thread'][0]} x {info['one_thread'][1]} "
                        f"at 1 thread); value = the faster of the two")
 
 
-def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2):
+def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2, cpu_threads=0, cpu_budget=14.0):
     """BASELINE.json configs[3]: A-GCN (per-sample adaptive adjacency) clip forward and CoAGCN online step at the
-    Kinetics-400 shape (V = 18, T = 300), synthetic inputs resident in HBM, random-init weights."""
-    A, shape = pkg.kinetics_graph().A, (3, 300, 18, 2)
+    Kinetics-400 shape (V = 18, T = 300), synthetic inputs resident in HBM, random-init weights.  Both legs carry the
+    whole-config roofline (tools/workmodel.py with the A-GCN terms: embedding convs, attention logits, dense
+    aggregation -- all of it executed, so frac == frac_executed) and, when cpu_threads > 0, the CPU oracle beside them."""
+    A, shape = pkg.kinetics_graph().A, KIN_SHAPE
+    V, M = shape[2], shape[3]
+    cpu_clip = cpu_step = None
+    if cpu_threads > 0:
+        cpu_clip = cpu_baseline_clip(0, cpu_threads, budget_s=0.55 * cpu_budget, adaptive=True)
+        cpu_step = cpu_baseline_step(0, cpu_threads, budget_s=0.45 * cpu_budget, adaptive=True)
     net = pkg.AGcn(A, shape, 400).eval()
-    randomise_(net, 0)
+    randomise_(net, 0, attn_scale=1 / 18)
     net = net.to(dev)
     x = torch.rand((batch,) + shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
     for _ in range(2):
-        net(x)
+        out = net(x)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        net(x)
+        out = net(x)
     torch.cuda.synchronize()
     clip_dt = (time.perf_counter() - t0) / 5
-    del net, x
+    assert out.shape == (batch, 400) and bool(torch.isfinite(out).all())
+    del net, x, out
 
     def make():
         co = pkg.CoAGcn(A, shape, 400).eval()
-        randomise_(co, 0)
+        randomise_(co, 0, attn_scale=1 / 18)
         return co.to(dev)
     eng = parallel.StreamShards(make, streams, shards, dev)
-    frames = torch.rand((8, streams) + (3, 18, 2), device=dev, generator=torch.Generator(device=dev).manual_seed(8))
-    for t in range(76 + 8):
+    frames = torch.rand((8, streams) + (3, V, M), device=dev, generator=torch.Generator(device=dev).manual_seed(8))
+    for t in range(76 + 4 * (75 - 19 - 1)):       # warm-up + fill the temporal pool, as the CoST-GCN leg
         eng.forward_cycle([frames[t % 8]])
+    for c in range(2):
+        eng.forward_cycle([frames[(4 * c + f) % 8] for f in range(4)])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for c in range(12):
-        eng.forward_cycle([frames[(4 * c + f) % 8] for f in range(4)])
+        out = eng.forward_cycle([frames[(4 * c + f) % 8] for f in range(4)])
     torch.cuda.synchronize()
     step_dt = (time.perf_counter() - t0) / 12
+    assert out is not None and out.shape == (streams, 400) and bool(torch.isfinite(out).all())
+    sbytes = eng.state_bytes()
     del eng
     gc.collect()
     torch.cuda.empty_cache()
+    cfa, cfe, cby = workmodel.clip_totals(batch * M, V=V, adaptive=True)
+    sfa, sfe, sby = workmodel.step_totals(streams * M, 4, V=V, adaptive=True)
     return {"config": "BASELINE.json configs[3], Kinetics-400 shape (3,300,18,2), fp32, synthetic, per GPU",
-            "agcn_clip": {"value": round(batch / clip_dt, 1), "unit": "clips/s", "batch": batch, "ms_per_step": round(clip_dt * 1e3, 3)},
+            "agcn_clip": {"value": round(batch / clip_dt, 1), "unit": "clips/s", "batch": batch, "ms_per_step": round(clip_dt * 1e3, 3),
+                          "roofline_config": workmodel.roofline_config(cfa, cby, clip_dt, cfe), "cpu_baseline": cpu_clip},
             "coagcn_online": {"value": round(4 * streams / step_dt, 1), "unit": "frames/s", "streams": streams,
-                              "stream_shards": shards, "frames_per_launch": 4, "ms_per_frame_step": round(step_dt / 4 * 1e3, 4)}}
+                              "stream_shards": shards, "frames_per_launch": 4, "ms_per_frame_step": round(step_dt / 4 * 1e3, 4),
+                              "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
+                              "roofline_config": workmodel.roofline_config(sfa, sby, step_dt, sfe), "cpu_baseline": cpu_step}}
 
 
 def load_traffic(name="traffic_tcn_stage.json"):
@@ -313,8 +349,13 @@ def main():
     ap.add_argument("--step-cycles", type=int, default=16, help="timed 4-frame cycles of the online workload")
     ap.add_argument("--stream-shards", type=int, default=2, help="independent stream shards on separate HIP streams")
     ap.add_argument("--frames-per-launch", type=int, default=4, help="frames advanced per launch cycle of the online workload")
+    ap.add_argument("--config5-batch", type=int, default=1024,
+                    help="clips per GPU of the configs[4] leg (8192 / 8 GPUs), run when more than one rank is launched")
+    ap.add_argument("--config4-batch", type=int, default=64, help="A-GCN clips of the configs[3] clip leg")
+    ap.add_argument("--config4-streams", type=int, default=1024, help="CoAGCN streams of the configs[3] online leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=50.0, help="seconds of CPU work the cpu_baseline legs may take in all")
+    ap.add_argument("--cpu-budget", type=float, default=50.0, help="seconds of CPU work the configs[1]/[2] cpu_baseline legs may take in all")
+    ap.add_argument("--cpu-budget-config4", type=float, default=14.0, help="seconds of CPU work for the two configs[3] cpu_baseline legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -328,7 +369,10 @@ def main():
     # N > 1 code path of this script on a 1-GPU box; real runs use the default, "nccl" = RCCL, one rank per GPU
     backend = os.environ.get("CSK_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
+    # CSK_BENCH_FORCE_DIST=1: initialise the process group and run every collective of the N > 1 path with ONE rank as
+    # well (what a 1-GPU box can exercise of RCCL: tests/test_gpu_multirank.py)
+    use_dist = world > 1 or (os.environ.get("CSK_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
@@ -353,45 +397,68 @@ def main():
 
     def max_over_ranks(v):
         t = torch.tensor([v], device=dev, dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def ranks_seen():
+        """Distinct (hostname, device) pairs among the ranks: == world when every rank has a GPU of its own."""
+        if not use_dist:
+            return 1
+        import hashlib
+        import socket
+        try:
+            ident = f"{socket.gethostname()}/{torch.cuda.get_device_properties(dev).uuid}"
+        except Exception:
+            ident = f"{socket.gethostname()}/{dev_index}"
+        h = int.from_bytes(hashlib.sha1(ident.encode()).digest()[:7], "little")
+        mine = torch.tensor([h], device=dev, dtype=torch.int64)
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        return len({int(t.item()) for t in allh})
+
     line = None
     B = args.batch
-    if do_clip:
+
+    def clip_leg(batch, steps, warmup, seed0=100):
+        """`steps` timed clip forwards of `batch` clips per rank (+ the logit all-gather when ranks > 1), bracketed by
+        barrier + synchronize; returns (max-over-ranks seconds, tcn_stage HIP-event ms, launches timed)."""
         net = pkg.StGcn(pkg.ntu_graph().A, input_shape=(NTU["C"], NTU["T"], NTU["V"], NTU["M"]), num_classes=NTU["classes"]).eval()
         randomise_(net, seed=0)                              # identical weights on every rank
         net = net.to(dev)
-        x = torch.rand((B, NTU["C"], NTU["T"], NTU["V"], NTU["M"]), device=dev,
-                       generator=torch.Generator(device=dev).manual_seed(100 + rank))
+        x = torch.rand((batch, NTU["C"], NTU["T"], NTU["V"], NTU["M"]), device=dev,
+                       generator=torch.Generator(device=dev).manual_seed(seed0 + rank))
 
         def step():
             logits = net(x)
-            return parallel.all_gather_logits(logits) if world > 1 else logits
+            return parallel.all_gather_logits(logits) if use_dist else logits
 
         with LaunchTimer(pkg, "tcn_stage") as lt:
-            for _ in range(args.warmup):
+            for _ in range(warmup):
                 out = step()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             lt.enabled = True
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 out = step()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             lt.enabled = False
             tcn_ms = lt.total_ms()
             n_launch = len(lt.records)
-        assert out.shape == (B * world, NTU["classes"]) and bool(torch.isfinite(out).all())
+        assert out.shape == (batch * world, NTU["classes"]) and bool(torch.isfinite(out).all())
         dt = max_over_ranks(dt)
         del x, out, net
         gc.collect()                 # engines hold reference cycles (state-dict hooks); free their slabs now
         torch.cuda.empty_cache()
+        return dt, tcn_ms, n_launch
+
+    if do_clip:
+        dt, tcn_ms, n_launch = clip_leg(B, args.steps, args.warmup)
         clips = B * world * args.steps
         flops_launch = tcn_flops_per_clip_forward(B * NTU["M"]) / 10.0       # average over the 10 launches / step
         avg_launch_s = tcn_ms / 1e3 / max(1, n_launch)
@@ -421,15 +488,30 @@ def main():
             # non-zeros the sparse kernel executes under flops_executed
             "roofline_config": workmodel.roofline_config(cfa * world, cby * world, dt / args.steps, cfe * world),
             "cpu_baseline": cpu,
+            "ranks_seen": ranks_seen(), "collective_backend": backend if use_dist else None,
         }
+        if use_dist:
+            # BASELINE.json configs[4]: batch 8192 over 8 GPUs = 1024 clips per GPU + the RCCL logit all-gather.  Reported
+            # beside the 256 / GPU weak-scaling headline (which stays comparable with the N = 1 line); at N = 8 this IS
+            # configs[4], at other N the same per-GPU shard.
+            b5 = args.config5_batch
+            steps5 = max(2, args.steps // 4)
+            dt5, _, _ = clip_leg(b5, steps5, 1, seed0=300)
+            f5a, f5e, f5y = workmodel.clip_totals(b5 * NTU["M"])
+            line["config5"] = {
+                "workload": f"ST-GCN clip inference, {b5} clips/GPU x {world} GPUs = global batch {b5 * world}, logit all-gather "
+                            f"over {backend} [configs[4]{'' if (b5 == 1024 and world == 8) else ' per-GPU shard shape'}]",
+                "value": round(b5 * world * steps5 / dt5, 2), "unit": "clips/s", "clips_per_gpu": b5, "global_batch": b5 * world,
+                "steps": steps5, "ms_per_step": round(dt5 / steps5 * 1e3, 3),
+                "roofline_config": workmodel.roofline_config(f5a * world, f5y * world, dt5 / steps5, f5e * world)}
 
     if do_step:
-        sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist, args.stream_shards, fpl=args.frames_per_launch)
+        sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist, args.stream_shards, fpl=args.frames_per_launch, use_dist=use_dist)
         sdt = max_over_ranks(sdt)
         # kernel-level timing: launches must not overlap and must go through the Python hook -> short single-shard pass
         gc.collect()                 # engines hold reference cycles (state-dict hooks); free their slabs now
         torch.cuda.empty_cache()
-        _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1, native_plan=False)
+        _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1, native_plan=False, use_dist=use_dist)
         kcycles = 4
         # the timed launches are the tcn_step_kernel launches of a cycle: blocks 5-10 (blocks 1-4, C_out = 64, advance with
         # the fused csk_co_block_step_f32 launch, which does not go through the hook)
@@ -445,12 +527,12 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             tdt, _, _, _ = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist,
-                                             args.stream_shards, fpl=8)
+                                             args.stream_shards, fpl=8, use_dist=use_dist)
             tdt = max_over_ranks(tdt)
-            tfa, _, tby = workmodel.step_totals(args.streams * NTU["M"], 8)
+            tfa, tfe, tby = workmodel.step_totals(args.streams * NTU["M"], 8)
             thr = {"frames_per_launch": 8, "value": round(8 * args.streams * world * args.step_cycles / tdt, 1),
                    "unit": "frames/s",
-                   "roofline_config_frac": workmodel.roofline_config(tfa * world, tby * world, tdt / args.step_cycles)["frac"]}
+                   "roofline_config_frac": workmodel.roofline_config(tfa * world, tby * world, tdt / args.step_cycles, tfe * world)["frac"]}
         step_info = {"metric": "skeleton frames/sec (CoST-GCN online step, NTU-60 shape)", "value": round(fps, 1),
                      "unit": "frames/s", "streams_per_gpu": args.streams, "stream_shards": args.stream_shards, "frames_per_launch": args.frames_per_launch, "ms_per_frame_step": round(sdt / args.step_cycles / args.frames_per_launch * 1e3, 4),
                      "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
@@ -479,10 +561,14 @@ def main():
     if do_clip and do_step and world == 1:          # BASELINE.json configs[3] beside the headline numbers (per GPU)
         gc.collect()
         torch.cuda.empty_cache()
-        line["agcn_kinetics"] = run_config4(pkg, dev, parallel)
+        line["agcn_kinetics"] = run_config4(pkg, dev, parallel, batch=args.config4_batch, streams=args.config4_streams,
+                                            shards=args.stream_shards, cpu_threads=0 if args.no_cpu_baseline else host_cpu_threads(),
+                                            cpu_budget=args.cpu_budget_config4)
+    line.setdefault("ranks_seen", ranks_seen())
+    line.setdefault("collective_backend", backend if use_dist else None)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -120,11 +120,23 @@ class CoTemporalConvolution(TemporalConvolution):
 class _BlockState:
     """Slice of the state slab owned by one block: y ring, output ring, (optionally own) input ring, counters."""
 
-    def __init__(self, c_in, c_out, k, p, device, xin=None, ksplit=1):
+    def __init__(self, c_in, c_out, k, p, device, xin=None, ksplit=1, max_emit=MAX_CYCLE, scratch=None):
         self.p = p
         self.ksplit = ksplit
-        # split-K scratch of the TCN step (latency mode): raw partial sums of up to MAX_CYCLE emissions
-        self.partial = torch.empty((MAX_CYCLE * ksplit, c_out, p), device=device, dtype=torch.float32) if ksplit > 1 else None
+        # split-K scratch of the TCN step: raw partial sums of the emissions ONE launch can produce (max_emit: MAX_CYCLE
+        # for a stand-alone block, MAX_CYCLE / cumulative stride inside a stack).  Launches are stream-ordered, so a
+        # stack shares one scratch buffer (``scratch``, sized by its largest user) instead of one per block.
+        self.max_emit = max_emit
+        self.owns_partial = ksplit > 1 and scratch is None
+        need = max_emit * ksplit * c_out * p
+        if ksplit <= 1:
+            self.partial = None
+        elif scratch is not None:
+            if scratch.numel() < need:
+                raise ValueError(f"shared split-K scratch holds {scratch.numel()} floats, block needs {need}")
+            self.partial = scratch[:need].view(max_emit * ksplit, c_out, p)
+        else:
+            self.partial = torch.empty((max_emit * ksplit, c_out, p), device=device, dtype=torch.float32)
         self.y = torch.zeros((YRING, c_out, p), device=device, dtype=torch.float32)
         self.out = torch.zeros((HIST, c_out, p), device=device, dtype=torch.float32)
         self.owns_xin = xin is None
@@ -140,7 +152,11 @@ class _BlockState:
         self.s = self.e = 0
 
     def nbytes(self):
+        """Persistent state of this block (rings); the split-K scratch is reported by scratch_bytes()."""
         return 4 * (self.y.numel() + self.out.numel() + (self.xin.numel() if self.owns_xin else 0))
+
+    def scratch_bytes(self):
+        return 4 * self.partial.numel() if self.owns_partial else 0
 
 
 class CoSpatioTemporalBlock(SpatioTemporalBlock):
@@ -209,11 +225,18 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         return fold.fold_block_tail(sd, "", has_conv_residual=self.kind == "conv")
 
     # ---- persistent state --------------------------------------------------------------------------
-    def bind_state(self, p: int, device, xin: Optional[torch.Tensor] = None) -> _BlockState:
-        """(Re)allocate this block's slab slice for P positions; ``xin`` = upstream block's output ring."""
+    def bind_state(self, p: int, device, xin: Optional[torch.Tensor] = None, max_emit: int = MAX_CYCLE,
+                   scratch: Optional[torch.Tensor] = None) -> _BlockState:
+        """(Re)allocate this block's slab slice for P positions; ``xin`` = upstream block's output ring; ``max_emit`` =
+        emissions one launch of this block can produce; ``scratch`` = split-K scratch shared with the other blocks."""
         self._state = _BlockState(self.in_channels, self.out_channels, self.kernel_size, p, device, xin,
-                                  ksplit=self._pick_ksplit(p))
+                                  ksplit=self._pick_ksplit(p), max_emit=max_emit, scratch=scratch)
         return self._state
+
+    def scratch_floats(self, p: int, max_emit: int = MAX_CYCLE) -> int:
+        """Split-K scratch this block needs for launches of up to ``max_emit`` emissions (0 without split-K)."""
+        ks = self._pick_ksplit(p)
+        return max_emit * ks * self.out_channels * p if ks > 1 else 0
 
     split_k = 0     # 0: no split-K; n > 1: latency mode -- up to n channel ranges per tile when a launch is too small
 
@@ -272,12 +295,17 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         lag = (k - 1) // 2              # emission s pairs with input frame s - 4 (co.Delay / residual_shrink)
         mode = {"none": 0, "identity": 1, "conv": 2}[self.kind]
         slot0 = st.e % HIST
-        blocks.tcn_step_launch(
-            native.ptr(st.y), YRING, first % YRING, self.stride, n_emit, native.ptr(ops["w"]),
-            native.ptr(st.xin) if mode else None, HIST, (first - lag) % HIST, self.stride,
-            native.ptr(ops["w_res"]), native.ptr(ops["bias"]), native.ptr(st.out), HIST, slot0,
-            self.out_channels, self.out_channels, p, k, mode, self.in_channels if mode else 0, 1,
-            st.ksplit, native.ptr(st.partial) if st.partial is not None else None, native.stream_of(st.y))
+        # one launch; with split-K at most max_emit emissions per launch (the scratch holds that many partial sums) --
+        # only the end-padding flush of a stack exceeds it (per-output summation order does not depend on the grouping)
+        group = n_emit if st.partial is None else min(n_emit, st.max_emit)
+        for e0 in range(0, n_emit, group):
+            ne, f0 = min(group, n_emit - e0), first + e0 * self.stride
+            blocks.tcn_step_launch(
+                native.ptr(st.y), YRING, f0 % YRING, self.stride, ne, native.ptr(ops["w"]),
+                native.ptr(st.xin) if mode else None, HIST, (f0 - lag) % HIST, self.stride,
+                native.ptr(ops["w_res"]), native.ptr(ops["bias"]), native.ptr(st.out), HIST, (slot0 + e0) % HIST,
+                self.out_channels, self.out_channels, p, k, mode, self.in_channels if mode else 0, 1,
+                st.ksplit, native.ptr(st.partial) if st.partial is not None else None, native.stream_of(st.y))
         st.e += n_emit
         return slot0, n_emit
 
@@ -413,6 +441,7 @@ class CoStGcn(_Folded):
             pool_padding = pool_size - math.ceil((t - self.receptive_field + self.padding + 1) / self.stride)
         self.pool_size, self.pool_padding = pool_size, max(0, pool_padding)
         self._n = None
+        self._flushed = False
 
     # ---- weights ---------------------------------------------------------------------------------
     def map_state_dict(self, state_dict, strict=True):
@@ -445,28 +474,33 @@ class CoStGcn(_Folded):
         p = _round4(n * m * v)
         xin = torch.zeros((HIST, c_in, p), device=device, dtype=torch.float32)
         self._xin0, self._p, self._n = xin, p, n
+        # emissions one launch of block i can produce: MAX_CYCLE input frames / cumulative temporal stride; the split-K
+        # scratch is ONE buffer sized by its largest user (launches of a model are stream-ordered)
+        emits, cum = [], 1
         for i in range(10):
-            st = self.layers[f"layer{i + 1}"].bind_state(p, device, xin)
+            cum *= self.layers[f"layer{i + 1}"].stride
+            emits.append(max(1, MAX_CYCLE // cum))
+        need = max(self.layers[f"layer{i + 1}"].scratch_floats(p, emits[i]) for i in range(10))
+        self._scratch = torch.empty((need,), device=device, dtype=torch.float32) if need else None
+        for i in range(10):
+            st = self.layers[f"layer{i + 1}"].bind_state(p, device, xin, max_emit=emits[i], scratch=self._scratch)
             xin = st.out
         self._pool_ring = torch.zeros((self.pool_size, n, 256), device=device, dtype=torch.float32)
         self._pooled = torch.empty((n, 256), device=device, dtype=torch.float32)
         self._frames = self._feats = 0
+        self._flushed = False
         self._build_plan(device)
 
-    _plan_graphs = False
-
-    def set_latency_mode(self, split_k: int = 8, graphs: bool = False):
+    def set_latency_mode(self, split_k: int = 8):
         """Few-stream operation (one camera, a handful of streams): the TCN step of a block then holds one workgroup
         per tile that walks all 9*C/8 K-chunks alone (123 us at C = 256).  With ``split_k`` > 1 such launches cut the
         channel axis into up to ``split_k`` ranges computed by separate workgroups and summed in a fixed order
         (csk_tcn_step_f32 ``ksplit``); launches that fill the GPU anyway are left alone.  Results differ from the
-        default by fp32 summation order only.  ``graphs``: the native executor replays the block launches of a frame
-        from hipGraphs (csk_co_plan_set_graphs; bit-identical, but measured SLOWER than eager launches on ROCm 7.2:
-        0.41 vs 0.36 ms per frame-step, so it is off by default).  Takes effect from a clean state (the slab is
-        re-bound)."""
+        default by fp32 summation order only.  Takes effect from a clean state (the slab is re-bound).  (Replaying a
+        frame's launches from hipGraphs was built and measured slower than eager launches on ROCm 7.2 -- 0.41 vs 0.36 ms per
+        frame-step -- and removed: profiles/HISTORY.md.)"""
         for i in range(10):
             self.layers[f"layer{i + 1}"].split_k = int(split_k)
-        self._plan_graphs = bool(graphs)
         self._n = None
 
     # ---- native executor ---------------------------------------------------------------------------
@@ -474,6 +508,48 @@ class CoStGcn(_Folded):
         """Identity + version of every parameter / buffer AS THEY ARE NOW (not as captured at bind time): an in-place
         edit bumps _version, load_state_dict(assign=True) or swapping a sub-module changes id / data_ptr."""
         return tuple((id(t), t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    _VERIFY_PER_CYCLE = 24      # tensors re-checked per cycle by the rotating window of _weights_changed
+
+    def _mark_weights_dirty(self, *args, **kwargs):
+        self.__dict__["_weights_dirty"] = True
+
+    def _install_dirty_hooks(self):
+        """load_state_dict on the model or ANY sub-module and .to() / .float() / ... (``_apply``) flag the plan's operands
+        as stale immediately; see _weights_changed for in-place edits."""
+        if self.__dict__.get("_dirty_hooks"):
+            return
+        for m in self.modules():
+            m.register_load_state_dict_post_hook(lambda mod, keys, net=self: net._mark_weights_dirty())
+        self.__dict__["_dirty_hooks"] = True
+
+    def _apply(self, fn, *args, **kwargs):
+        self._mark_weights_dirty()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _weights_changed(self) -> bool:
+        """Hot-path staleness check of the native plan (one call per cycle; the full walk of ~240 tensors costs ~0.4 ms of
+        host time, which in latency mode is a whole GPU cycle).  Exact and immediate for load_state_dict / .to() (dirty
+        flag set by hooks) and for a swapped sub-module or parameter count (cheap structural check); in-place edits of
+        single tensors (``p.data.mul_(..)``) are found by a rotating window that re-reads data_ptr / _version of
+        _VERIFY_PER_CYCLE cached tensors per cycle, i.e. within len(tensors) / _VERIFY_PER_CYCLE (~10) cycles -- call
+        ``refold()`` after such an edit to apply it at once."""
+        if self.__dict__.pop("_weights_dirty", False):
+            return True
+        keep = self._plan_keep
+        ts, ver = keep[2], keep[1]
+        n = len(ts)
+        i0 = self.__dict__.get("_verify_pos", 0)
+        for j in range(i0, min(i0 + self._VERIFY_PER_CYCLE, n)):
+            t = ts[j]
+            if (id(t), t.data_ptr(), t._version) != ver[j]:
+                return True
+        self.__dict__["_verify_pos"] = 0 if i0 + self._VERIFY_PER_CYCLE >= n else i0 + self._VERIFY_PER_CYCLE
+        return False
+
+    def refold(self):
+        super().refold()
+        self._mark_weights_dirty()
 
     def _layer_structs(self, device):
         """(ctypes array of csk_co_layer, objects to keep alive) from the blocks' packed operands and state."""
@@ -517,9 +593,9 @@ class CoStGcn(_Folded):
         if not plan:
             raise RuntimeError("csk_co_plan_create: " + native.lib().csk_last_error().decode())
         self.__dict__["_plan"] = plan
-        self.__dict__["_plan_keep"] = (keep, self._weights_version())
-        if self._plan_graphs:
-            native.check(native.lib().csk_co_plan_set_graphs(plan, 1), "csk_co_plan_set_graphs")
+        self._install_dirty_hooks()
+        self.__dict__["_plan_keep"] = (keep, self._weights_version(), list(self.parameters()) + list(self.buffers()))
+        self.__dict__.pop("_weights_dirty", None)
         fuse = all(self.layers[f"layer{i + 1}"].fuse_step for i in range(10))
         native.check(native.lib().csk_co_plan_set_fusion(plan, int(fuse)), "csk_co_plan_set_fusion")
 
@@ -531,7 +607,8 @@ class CoStGcn(_Folded):
         rc = native.lib().csk_co_plan_update_weights(self._plan, 10, ctypes.byref(arr), native.ptr(ops["scale"]),
                                                      native.ptr(ops["shift"]), native.ptr(fcw), native.ptr(fcb))
         native.check(rc, "csk_co_plan_update_weights")
-        self.__dict__["_plan_keep"] = (keep, self._weights_version())
+        self.__dict__["_plan_keep"] = (keep, self._weights_version(), list(self.parameters()) + list(self.buffers()))
+        self.__dict__["_verify_pos"] = 0
 
     def _destroy_plan(self):
         plan = self.__dict__.pop("_plan", None)
@@ -546,8 +623,13 @@ class CoStGcn(_Folded):
             pass
 
     def state_bytes(self):
+        """Persistent continual state (input ring, per-block rings, pooling window)."""
         return sum(self.layers[f"layer{i + 1}"]._state.nbytes() for i in range(10)) + 4 * (
             self._xin0.numel() + self._pool_ring.numel())
+
+    def scratch_bytes(self):
+        """Transient split-K scratch (shared by the blocks that split their K loop); not state."""
+        return 4 * self._scratch.numel() if self._scratch is not None else 0
 
     def clean_state(self):
         if self._n is not None:
@@ -556,6 +638,7 @@ class CoStGcn(_Folded):
                 self.layers[f"layer{i + 1}"].clean_state()
             self._pool_ring.zero_()
             self._frames = self._feats = 0
+            self._flushed = False
             if self.__dict__.get("_plan"):
                 native.lib().csk_co_plan_reset(self._plan)
 
@@ -578,6 +661,9 @@ class CoStGcn(_Folded):
             raise RuntimeError(f"frame shape {tuple(x0.shape)} does not match input_shape {self.input_shape}")
         if self._n != n or self._xin0.device != x0.device:           # clean_state_on_shape_change (base.py:161-164)
             self._bind(n, x0.device)
+        if self._flushed:
+            raise RuntimeError("the state was flushed by forward_steps(pad_end=True): the end padding has consumed ring slots "
+                               "and advanced the blocks past the input frame count; call clean_state() before stepping on")
         if self.__dict__.get("_plan"):
             return self._plan_cycle(frames)
         return self._python_cycle(frames)
@@ -614,7 +700,7 @@ class CoStGcn(_Folded):
             self._bind(x_t.shape[0], x_t.device)
 
     def _plan_cycle(self, frames):
-        if self._plan_keep[1] != self._weights_version():
+        if self._weights_changed():
             self._refresh_plan_weights(frames[0].device)
         n = frames[0].shape[0]
         ptrs = (ctypes.c_void_p * len(frames))(*[x_t.data_ptr() for x_t in frames])
@@ -710,13 +796,14 @@ class CoStGcn(_Folded):
         frames, and the temporal average pool is flushed with ``pool_padding`` zero features."""
         if not update_state:                       # several frames overwrite live window slots: keep a copy of the slab
             self._ensure_bound(x[:, :, 0].contiguous())
-            snap, keep = self._counters(), [t.clone() for t in self._state_tensors()]
+            snap, keep, flushed = self._counters(), [t.clone() for t in self._state_tensors()], self._flushed
             try:
                 return self.forward_steps(x, pad_end, True)
             finally:
                 for t, k in zip(self._state_tensors(), keep):
                     t.copy_(k)
                 self._set_counters(snap)
+                self._flushed = flushed
         outs = []
         for t in range(x.shape[2]):
             o = self.forward_step(x[:, :, t].contiguous())
@@ -724,13 +811,18 @@ class CoStGcn(_Folded):
                 outs.append(o)
         if pad_end and x.shape[2] > 0:
             outs += self._flush()
+            self._flushed = True                   # stepping on needs clean_state() (see _flush)
         if not outs:
             return torch.empty((x.shape[0], self.num_classes, 0), device=x.device)
         return torch.stack(outs, dim=2)
 
     def _flush(self):
         """End padding of the whole model (``pad_end=True``): returns the predictions it releases.  Runs on the Python
-        engine; a native plan's counters are read before and written back afterwards."""
+        engine; a native plan's counters are read before and written back afterwards.  The flush ends the sequence: it
+        zeroes y-ring slots and advances the per-block counters by their padding while the input frame count stays,
+        so the rings no longer line up with ``frames % HIST`` -- the model is marked flushed and the next step raises
+        until ``clean_state()`` (continual-inference's own end padding does not save state either; a caller that wants
+        to go on uses ``update_state=False``, which runs the flush on a snapshot)."""
         plan = self.__dict__.get("_plan")
         if plan:
             buf = (ctypes.c_int64 * 22)()

@@ -1,8 +1,6 @@
 // executor.hip -- native step executor for the continual stack (host code only; launches go through the C ABI
 // entry points of gcn.hip / step.hip / head.hip).  Mirrors continual.py:CoSpatioTemporalBlock.engine_advance and
 // CoStGcn.features_cycle / _head_step one to one; the Python versions remain the reference for the protocol.
-#include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "mfma_core.h"
@@ -21,26 +19,7 @@ struct csk_co_plan {
     const float *bn_scale, *bn_shift, *fc_w, *fc_b;
     float *pool_ring, *pooled;
     long frames = 0, feats = 0;
-    // hipGraph replay of the ten blocks (latency mode).  A cycle's launch sequence and every kernel argument are a
-    // function of (r, per-layer s mod 16, e mod 16, warm-up state): 64 distinct keys in steady per-frame stepping.  A
-    // key is run eagerly the first time, captured the second time, replayed afterwards.
-    struct GraphSlot { hipGraphExec_t exec = nullptr; int seen = 0; };
-    bool use_graphs = false;
     bool fuse = true;          // csk_co_block_step_f32 for the blocks that qualify
-    hipStream_t gstream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    std::unordered_map<std::string, GraphSlot> graphs;
-    void drop_graphs() {
-        for (auto &kv : graphs)
-            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        graphs.clear();
-    }
-    ~csk_co_plan() {
-        drop_graphs();
-        if (ev_in) (void)hipEventDestroy(ev_in);
-        if (ev_out) (void)hipEventDestroy(ev_out);
-        if (gstream) (void)hipStreamDestroy(gstream);
-    }
 };
 
 extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int N, int C, int V,
@@ -88,27 +67,12 @@ extern "C" int csk_co_plan_update_weights(csk_co_plan *plan, int n_layers, const
     }
     plan->layers.assign(layers, layers + n_layers);
     plan->bn_scale = bn_scale; plan->bn_shift = bn_shift; plan->fc_w = fc_w; plan->fc_b = fc_b;
-    plan->drop_graphs();                 // captured kernel arguments hold the old operand pointers
-    return 0;
-}
-
-extern "C" int csk_co_plan_set_graphs(csk_co_plan *plan, int enable) {
-    if (!plan) CSK_FAIL("co_plan_set_graphs: null pointer");
-    if (enable && !plan->gstream) {
-        hipError_t e = hipStreamCreateWithFlags(&plan->gstream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&plan->ev_in, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&plan->ev_out, hipEventDisableTiming);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (!enable) plan->drop_graphs();
-    plan->use_graphs = enable != 0;
     return 0;
 }
 
 extern "C" int csk_co_plan_set_fusion(csk_co_plan *plan, int enable) {
     if (!plan) CSK_FAIL("co_plan_set_fusion: null pointer");
     plan->fuse = enable != 0;
-    plan->drop_graphs();                 // captured launch sequences differ
     return 0;
 }
 
@@ -134,16 +98,15 @@ extern "C" void csk_co_plan_reset(csk_co_plan *plan) {
 }
 
 // one block: r frames are already in xin[(s .. s+r-1) % HIST]; returns emissions via *slot0 / *n_emit
-// (launch = false: only the counters advance -- the launches of this state are replayed from a captured graph)
 static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *xin, int r, int n_frames, int V,
-                         int64_t P, int *slot0, int *n_emit, bool launch, bool fuse, void *stream) {
+                         int64_t P, int *slot0, int *n_emit, bool fuse, void *stream) {
     constexpr int K = 9, DELAY = 4, LAG = 4;      // padding="equal": delay = k-1-p = 4; residual lag (k-1)/2
     const long s0 = c.s;
     // one fused launch for a whole emitting 4-frame cycle of a 64-row block (continual.py:_fusable)
     if (fuse && r == 4 && l.stride == 1 && l.c_out <= 64 && s0 >= DELAY && l.res_kind != CSK_RES_CONV && l.tcn_ksplit <= 1 &&
         l.ell_cnt[0] <= 1 && l.ell_cnt[1] <= 1 && l.ell_cnt[2] <= 4 && ((64 + V - 2) / V + 1) * V <= 128) {
         *slot0 = (int)(c.e % CSK_CO_HIST);
-        const int rc = !launch ? 0 : csk_co_block_step_f32(xin, CSK_CO_HIST, (int)(s0 % CSK_CO_HIST), l.c_in, l.gcn_w, l.gcn_bias,
+        const int rc = csk_co_block_step_f32(xin, CSK_CO_HIST, (int)(s0 % CSK_CO_HIST), l.c_in, l.gcn_w, l.gcn_bias,
                                          l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, l.gcn_res_mode, l.y_ring, CSK_CO_YRING,
                                          (int)(s0 % CSK_CO_YRING), l.tcn_w, l.tcn_bias, l.res_kind,
                                          (int)((s0 - LAG) % CSK_CO_HIST), l.out_ring, CSK_CO_HIST, *slot0, l.c_out, n_frames, V, P,
@@ -158,7 +121,7 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
         int run = r - f;
         if (run > CSK_CO_HIST - (int)(s % CSK_CO_HIST)) run = CSK_CO_HIST - (int)(s % CSK_CO_HIST);
         if (run > CSK_CO_YRING - (int)(s % CSK_CO_YRING)) run = CSK_CO_YRING - (int)(s % CSK_CO_YRING);
-        const int rc = !launch ? 0 : csk_gcn_stage_f32(xin + (s % CSK_CO_HIST) * (int64_t)l.c_in * P,
+        const int rc = csk_gcn_stage_f32(xin + (s % CSK_CO_HIST) * (int64_t)l.c_in * P,
                                          l.y_ring + (s % CSK_CO_YRING) * (int64_t)l.c_out * P, l.gcn_w, l.gcn_bias,
                                          l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, 0, 0, run, l.c_in, l.c_out, n_frames, V,
                                          (int64_t)l.c_in * P, P, (int64_t)l.c_out * P, P, l.gcn_res_mode, stream);
@@ -173,7 +136,7 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
     if (first < 0) return 0;
     const int ne = (int)((s0 + r - 1 - first) / l.stride) + 1;
     *slot0 = (int)(c.e % CSK_CO_HIST);
-    const int rc = !launch ? 0 : csk_tcn_step_f32(l.y_ring, CSK_CO_YRING, (int)(first % CSK_CO_YRING), l.stride, ne, l.tcn_w,
+    const int rc = csk_tcn_step_f32(l.y_ring, CSK_CO_YRING, (int)(first % CSK_CO_YRING), l.stride, ne, l.tcn_w,
                                     l.res_kind ? xin : nullptr, CSK_CO_HIST, (int)((first - LAG) % CSK_CO_HIST), l.stride,
                                     l.tcn_w_res, l.tcn_bias, l.out_ring, CSK_CO_HIST, *slot0, l.c_out, l.c_out, P, K,
                                     l.res_kind, l.res_kind ? l.c_in : 0, 1, l.tcn_ksplit > 1 ? l.tcn_ksplit : 1, l.tcn_partial,
@@ -185,13 +148,13 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
 }
 
 // the ten blocks for r new frames: *n_last emissions of the last block starting at output-ring slot *slot0
-static int run_blocks(csk_co_plan *p, int r, bool launch, int *slot0, int *n_last, void *stream) {
+static int run_blocks(csk_co_plan *p, int r, int *slot0, int *n_last, void *stream) {
     const float *xin = p->xin0;
     int rr = r;
     *n_last = 0;
     for (size_t i = 0; i < p->layers.size(); ++i) {
         int ne = 0;
-        const int rc = advance_block(p->layers[i], p->cnt[i], xin, rr, p->N * p->M, p->V, p->P, slot0, &ne, launch, p->fuse, stream);
+        const int rc = advance_block(p->layers[i], p->cnt[i], xin, rr, p->N * p->M, p->V, p->P, slot0, &ne, p->fuse, stream);
         if (rc) return rc;
         if (ne == 0) return 0;
         rr = ne;
@@ -201,28 +164,14 @@ static int run_blocks(csk_co_plan *p, int r, bool launch, int *slot0, int *n_las
     return 0;
 }
 
-// everything the launch sequence of run_blocks and its kernel arguments depend on
-static std::string graph_key(const csk_co_plan *p, int r) {
-    std::string k(1 + 3 * p->cnt.size(), '\0');
-    k[0] = (char)r;
-    for (size_t i = 0; i < p->cnt.size(); ++i) {
-        const BlockCounters &c = p->cnt[i];
-        k[1 + 3 * i] = (char)(c.s % 16);                 // ring slots of the new frames (HIST = YRING = 16)
-        k[2 + 3 * i] = (char)(c.e % 16);                 // output-ring slot of the next emission
-        k[3 + 3 * i] = (char)(c.s < 15 ? c.s : 15);      // warm-up (s < delay: nothing emitted yet)
-    }
-    return k;
-}
-
 extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int r, float *logits, int *last_slot,
                                  int *n_feat, int *n_logits, void *stream) {
     if (!p || !frames || !logits || !last_slot || !n_feat || !n_logits) CSK_FAIL("co_plan_cycle: null pointer");
     if (r < 1 || r > CSK_CO_MAX_CYCLE) CSK_FAIL("co_plan_cycle: r must be in [1, %d]", CSK_CO_MAX_CYCLE);
     *n_feat = *n_logits = 0;
     *last_slot = 0;
-    // A launch can fail half way through a cycle (bad pointer, capture / instantiate error): the counters are then put
-    // back to their values on entry, so that plan, caller-side counters and the frames == cnt[0].s invariant of the
-    // graph key stay consistent.  (Ring slots already overwritten belong to frames older than every window or to the
+    // A launch can fail half way through a cycle (bad pointer, launch error): the counters are then put
+    // back to their values on entry, so that plan and caller-side counters stay consistent.  (Ring slots already overwritten belong to frames older than every window or to the
     // cycle that failed; re-running the cycle rewrites them.)
     struct Rollback {
         csk_co_plan *p; long frames, feats; std::vector<BlockCounters> cnt; bool armed = true;
@@ -237,38 +186,7 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
         p->frames++;
     }
     int rr = 0, slot0 = 0;
-    if (!p->use_graphs) {
-        if (const int rc = run_blocks(p, r, true, &slot0, &rr, stream)) return rc;
-    } else {
-        // the blocks run on the plan's own stream (a legacy / default caller stream cannot be captured), fenced by events
-        hipStream_t gs = p->gstream, cs = (hipStream_t)stream;
-        csk_co_plan::GraphSlot &g = p->graphs[graph_key(p, r)];
-        hipError_t e = hipEventRecord(p->ev_in, cs);
-        if (e == hipSuccess) e = hipStreamWaitEvent(gs, p->ev_in, 0);
-        if (e != hipSuccess) return (int)e;
-        int rc = 0;
-        if (g.exec) {                                   // replay: counters advance, launches come from the graph
-            rc = run_blocks(p, r, false, &slot0, &rr, gs);
-            if (!rc) rc = (int)hipGraphLaunch(g.exec, gs);
-        } else if (g.seen == 0) {                       // first visit: eager (also settles the per-kernel LDS caps)
-            g.seen = 1;
-            rc = run_blocks(p, r, true, &slot0, &rr, gs);
-        } else {                                        // second visit: capture, instantiate, launch
-            e = hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal);
-            if (e != hipSuccess) return (int)e;
-            rc = run_blocks(p, r, true, &slot0, &rr, gs);
-            hipGraph_t graph = nullptr;
-            e = hipStreamEndCapture(gs, &graph);
-            if (!rc && e != hipSuccess) rc = (int)e;
-            if (!rc) rc = (int)hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-            if (graph) (void)hipGraphDestroy(graph);
-            if (!rc) rc = (int)hipGraphLaunch(g.exec, gs);
-        }
-        if (rc) return rc;
-        e = hipEventRecord(p->ev_out, gs);
-        if (e == hipSuccess) e = hipStreamWaitEvent(cs, p->ev_out, 0);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (const int rc = run_blocks(p, r, &slot0, &rr, stream)) return rc;
     if (rr == 0) { rollback.armed = false; return 0; }
     *last_slot = slot0;
     *n_feat = rr;

@@ -1,8 +1,8 @@
 // gcn.hip -- GCN stage of the ST-GCN / A-GCN forward path (gfx950 / MI355X):
 //   y = ReLU( W' . agg(x) + b' + gcn_residual(x) )      models/base.py:260-270, models/a_gcn/a_gcn.py:48-69
-// Two kernels share GcnParams: gcn_stage_sparse_kernel (skeleton graphs: the aggregated B operand is formed on the
+// Two kernels share GcnParams: gcn_stage_sparse2_kernel (skeleton graphs: the aggregated B operand is formed on the
 // fly from register-resident adjacency entries) and gcn_stage_kernel (general: any / dense / per-sample / per-frame
-// adjacency, ELL tables in LDS, VALU aggregation into an LDS operand tile).  GEMM core: mfma_core.h.
+// adjacency, ELL tables in LDS, aggregation into an LDS operand tile).  GEMM core: mfma_core.h.
 #include <type_traits>
 
 #include "mfma_core.h"
@@ -23,7 +23,6 @@ struct GcnParams {
     int dense;   // src[e] == e for all subsets and columns (checked on the host side of the ABI by construction)
     int adj_per_frame;   // the (dense) adjacency varies per FRAME of a segment: index = seg * frames + frame
     int lds_frames;      // frames of adjacency staged per workgroup in that mode
-    unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup of the sparse kernel
     int fast_epi;        // channel strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
     int no_pair_reads;   // diagnostic (CSK_NO_PAIR_READS): general kernel aggregates with scalar LDS reads for even V too
     int no_vec;          // diagnostic (CSK_GCN_NOVEC): sparse kernel stages activations element-wise on every tile
@@ -250,273 +249,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
 
 // ------------------------------------------------------------------------------------------------
 // GCN stage, sparse-graph fast path: the aggregated B operand is formed ON THE FLY in the MFMA loop.
-// For skeleton graphs A_eff has <= 1 / 1 / 4 non-zeros per column in the self / inward / outward subsets
-// (NTU-25: 1/1/4, OpenPose-18: 1/1/3), so every lane keeps the <= 6 (LDS offset, weight) pairs of its two
-// output columns in registers and builds   B_r[c][q] = sum_e val * x[c][frame(q), src_e]   with <= 6 LDS reads
-// + FMAs per k-step, against 12-16 MFMAs (768-1024 cycles) that consume them.  No aggregated tile, no
-// aggregation phase, one barrier pair per 16 channels.  Dense / per-sample adjacencies (A-GCN) use the
-// general kernel above.
-// ------------------------------------------------------------------------------------------------
-static constexpr int KCG = CSK_CPAD;    // channels per barrier pair == the zero-padding granule of the packed weights
-
-template <int MT, bool CONVRES>
-__global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_sparse_kernel(const GcnParams p) {
-    constexpr int NT = 16384 / MT;
-    constexpr int WM = MT / 64;
-    constexpr int R = CONVRES ? 4 : 3;
-    constexpr int M4 = MT / 4;
-    constexpr int WB = R * KCG * M4 / NTHREADS;            // f32x4 of weights per thread per chunk (6 or 8 / 3 or 4)
-    constexpr int RPW = KCG / (NTHREADS / 64);             // activation rows per wave per chunk (4)
-    constexpr int NJ = MT == 128 ? 3 : 5;                  // 64-lane sweeps per activation row (span <= 192 / 320)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int V = p.V;
-    float *Wl = smem;                                      // [R][KCG][MT]
-    float *Bx = smem + R * KCG * MT;                       // [KCG][ldb]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
-    const int seg = (int)(wid / (p.mtiles * p.qtiles));
-    const int Q = p.frames * V;
-    const int qend = min(q0 + NT, Q);
-    const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
-    const int span = (tb - ta + 1) * V;
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, ph0 = 0, ph1 = 0, ph2 = 0, tq = 0;
-    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
-    // per-lane adjacency entries of the two output columns this lane feeds (B operand: column = lane & 31)
-    int eoff[2][6];
-    float eval[2][6];
-    int ioff[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
-        const int t = div_magic(q, p.vmagic);
-        const int w = q - t * V, fb = (t - ta) * V;
-        ioff[ni] = fb + w;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;          // subsets 0,1: one entry; subset 2: four
-            const bool have = k < p.ell_cnt[r];
-            const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
-            eoff[ni][e] = fb + (have ? p.ell_src[idx] : 0);
-            eval[ni][e] = have ? p.ell_val[idx] : 0.f;
-        }
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
-
-    const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
-    const float *wbase = p.w + m0;
-    // staging registers + chunk-invariant offsets
-    f32x4 wv[WB];
-    unsigned wgo[WB], wlo[WB];
-#pragma unroll
-    for (int u = 0; u < WB; ++u) {
-        const int e = u * NTHREADS + tid;                  // exact cover: R*KCG*M4 is a multiple of 256
-        const int row = e / M4, m4 = e % M4;
-        wgo[u] = (unsigned)(((row / KCG) * p.CinPad + (row % KCG)) * p.Mpad + m4 * 4);
-        wlo[u] = (unsigned)(e * 4);
-    }
-    float bv[RPW][NJ];
-    unsigned bgo[NJ], blo[NJ];
-#pragma unroll
-    for (int u = 0; u < NJ; ++u) {
-        const int j = min(u * 64 + lane, span - 1);
-        bgo[u] = (unsigned)(ta * V + j);                   // always inside [0, Q): whole frames of this segment
-        blo[u] = (unsigned)j;
-    }
-    auto issue_w = [&](int c0) {
-        const float *wc = wbase + (size_t)c0 * p.Mpad;
-#pragma unroll
-        for (int u = 0; u < WB; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(wc + wgo[u]);
-    };
-    auto issue_x = [&](int c0) {
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int c = c0 + wave + rr * (NTHREADS / 64);
-            const float *src = seg_base + (int64_t)min(c, p.Cin - 1) * p.x_chan_stride;
-            const float m = c < p.Cin ? 1.f : 0.f;
-#pragma unroll
-            for (int u = 0; u < NJ; ++u) bv[rr][u] = src[bgo[u]] * m;
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(Wl + wlo[u]) = wv[u];
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            float *dst = Bx + (wave + rr * (NTHREADS / 64)) * p.ldb;
-#pragma unroll
-            for (int u = 0; u < NJ; ++u) dst[blo[u]] = bv[rr][u];
-        }
-    };
-
-    const int offA = wm * 64 + l31;
-    const int cpad = p.CinPad;                             // multiple of CSK_CPAD == KCG (zero-padded weights)
-    auto mfma_steps = [&](int s_begin, int s_end) {
-#pragma unroll 2
-        for (int s = s_begin; s < s_end; ++s) {
-            const int kk = 2 * s + kh;
-            const float *bx = Bx + kk * p.ldb;
-            float b[R][2];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const float x0 = bx[eoff[ni][0]];
-                b[0][ni] = eval[ni][0] * x0;
-                b[1][ni] = eval[ni][1] * bx[eoff[ni][1]];
-                float s2 = eval[ni][2] * bx[eoff[ni][2]];
-                s2 = fmaf(eval[ni][3], bx[eoff[ni][3]], s2);
-                s2 = fmaf(eval[ni][4], bx[eoff[ni][4]], s2);
-                s2 = fmaf(eval[ni][5], bx[eoff[ni][5]], s2);
-                b[2][ni] = s2;
-                if (CONVRES) b[R - 1][ni] = bx[ioff[ni]];
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float *wr = Wl + (r * KCG + kk) * MT + offA;
-                const float a0 = wr[0], a1 = wr[32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][0], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[r][1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][0], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[r][1], acc[1][1], 0, 0, 0);
-            }
-        }
-    };
-    issue_w(0);
-    issue_x(0);
-    int c0 = 0;
-    if (p.stamps) tq = st1 = __builtin_amdgcn_s_memtime();
-    for (; c0 + KCG < cpad; c0 += KCG) {
-        __syncthreads();
-        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
-        commit();
-        __syncthreads();
-        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
-        issue_w(c0 + KCG);                                 // next chunk's loads fly underneath the MFMAs
-        issue_x(c0 + KCG);
-        __builtin_amdgcn_s_setprio(1);
-        mfma_steps(0, KCG / 2);
-        __builtin_amdgcn_s_setprio(0);
-        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
-    }
-    __syncthreads();                                       // peeled last chunk: the staging registers are dead,
-    commit();                                              // so the epilogue operands are loaded under its MFMAs
-    __syncthreads();
-    if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
-    // Epilogue operands.  Rows of this wave: rbase + mi*32 + (g & 3) + 8*(g >> 2) (+ 4*kh in the accumulator
-    // layout).  Everything but the lane's own offset is wave-uniform, so on full tiles (all MT rows exist) the
-    // row base pointers are formed on the scalar unit and each load / store carries one 32-bit lane offset; the
-    // general form (clamped rows, per-element predicates) costs ~13 instructions per access and is kept for
-    // ragged channel counts only.
-    const int rbase = m0 + wm * 64;
-    const bool full = p.fast_epi && m0 + MT <= p.Cout;
-    const unsigned kh4 = 4u * (unsigned)kh;
-    float bb[2][16], rv[2][2][16];
-    if (full) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) bb[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const unsigned lo = 4u * (kh4 * (unsigned)p.x_chan_stride + (unsigned)min(q0 + wn * 64 + ni * 32 + l31, Q - 1));
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const float *rrow = seg_base + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.x_chan_stride;
-                    rv[ni][mi][g] = CONVRES ? 0.f : ld_lane(rrow, lo);
-                }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) bb[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
-                    rv[ni][mi][g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
-                }
-        }
-    }
-    mfma_steps(0, KCG / 2);
-    unsigned long long st3 = 0;
-    if (p.stamps) st3 = __builtin_amdgcn_s_memtime();
-
-    // epilogue: ReLU(acc + bias + identity residual); permlane32_swap pairs the ni = 0/1 registers so that every
-    // store instruction writes one 256-B contiguous row segment (see tcn_stage_kernel)
-    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
-    const int qb = q0 + wn * 64 + lane;
-    const bool qv = qb < Q;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float v0 = relu_nan(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g]);
-            const float v1 = relu_nan(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g]);
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
-            acc[mi][0][g] = __uint_as_float(sw[0]);       // row (g & 3) + 8*(g >> 2), column qb
-            acc[mi][1][g] = __uint_as_float(sw[1]);       // row + 4
-        }
-    if (full) {
-        if (qv) {
-            const unsigned qo = 4u * (unsigned)qb;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.y_chan_stride;
-                    st_lane(orow, qo, acc[mi][0][g]);
-                    st_lane(orow + 4 * p.y_chan_stride, qo, acc[mi][1][g]);
-                }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
-                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = acc[mi][0][g];
-                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = acc[mi][1][g];
-            }
-    }
-    if (p.stamps && lane == 0) {   // [wg][wave][8]: start, loop start, last-chunk start, mfma end, end, wait/commit/mfma sums
-        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
-        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memtime(); o[5] = ph0; o[6] = ph1; o[7] = ph2;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Sparse-graph GCN stage, second form (the default): PING-PONG LDS, TRICKLED staging loads, THREE workgroups per CU.
-// Same arithmetic and summation order as gcn_stage_sparse_kernel (bitwise-equal results); what changes is the chunk
-// pipeline and the occupancy.  The first form spends per 16-channel chunk ~1.8-2.6 k of ~15-16 k cycles in [barrier,
-// commit, barrier] with the MFMA pipe idle on both co-resident workgroups (they run in lockstep), and issues the next
-// chunk's 18-23 global loads in one burst in front of the MFMAs (in-order waves: VMEM-issue stalls delay the first
-// MFMAs; measured 14.5 k cycles per MFMA segment at C = 256 against 12.3 k of MFMA work).  Here
-//   * LDS holds two chunk buffers: chunk c+1 is committed (registers -> LDS[other]) at the START of iteration c, in
-//     front of chunk c's MFMAs, so one barrier per chunk suffices (everybody done reading LDS[cur] and writing
-//     LDS[other]);
-//   * the loads of chunk c+2 are issued a few at a time between the first MFMA k-steps of chunk c (register prefetch
-//     one chunk ahead of the commit, as before), pinned there with sched_barrier;
+// For skeleton graphs A_eff has <= 1 / 1 / 4 non-zeros per column in the self / inward / outward subsets (NTU-25:
+// 1/1/4, OpenPose-18: 1/1/3), so every lane keeps the <= 6 (LDS offset, weight) pairs of its two output columns in
+// registers and builds   B_r[c][q] = sum_e val * x[c][frame(q), src_e]   with <= 6 LDS reads + FMAs per k-step, against
+// 12-16 MFMAs (768-1024 cycles) that consume them: no aggregated tile, no aggregation phase.  Dense / per-sample
+// adjacencies (A-GCN) use the general kernel above.  Chunk pipeline (history: profiles/HISTORY.md, round 2 item 14):
+//   * PING-PONG LDS: chunk c+1 is committed (registers -> LDS[other]) at the START of iteration c, in front of chunk c's
+//     MFMAs, so one barrier per chunk suffices (everybody done reading LDS[cur] and writing LDS[other]);
+//   * TRICKLED loads: the loads of chunk c+2 are issued a few at a time between the first MFMA k-steps of chunk c
+//     (register prefetch one chunk ahead of the commit), pinned there with sched_barrier;
 //   * the epilogue operands (32 biases + 64 residual values per lane) are loaded after the K loop, one 32-row half at
-//     a time, instead of being prefetched under the last chunk: with 8-channel chunks the kernel then fits 168
-//     registers and <= 45 KB of LDS, i.e. THREE workgroups per CU.  A third wave per SIMD is what pays here (-7..-13 %
-//     against the first form, in-process A/B tools/ab_gcn_probe.py; the same pipeline at two per CU: -1..-12 %): unlike
-//     the TCN loop, a GCN k-step carries 18 LDS reads + 14 VALU per 12 MFMAs whose latency another wave has to cover.
+//     a time: with 8-channel chunks the kernel fits 168 registers and <= 45 KB of LDS, i.e. THREE workgroups per CU --
+//     a GCN k-step carries 18 LDS reads + 14 VALU per 12 MFMAs whose latency a third wave per SIMD covers.
 // KCG_ = channels per chunk.
 // ------------------------------------------------------------------------------------------------
 template <int MT, bool CONVRES, int KCG_>
@@ -813,7 +557,6 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     // per-segment adjacencies are dense by contract (include/cskel.h): ell_w == V, ell_cnt == {V,V,V}, src[e] == e
     p.dense = adj_seg_stride != 0 && ell_w == V && ell_cnt[0] == V && ell_cnt[1] == V && ell_cnt[2] == V;
     p.adj_per_frame = adj_per_frame != 0;
-    p.stamps = csk_diag_stamps();
     p.no_pair_reads = csk_diag_flag("CSK_NO_PAIR_READS");
     p.no_vec = csk_diag_flag("CSK_GCN_NOVEC");
     // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
@@ -839,27 +582,21 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
         const int R = p.R;
         size_t lds2;
         void (*k)(GcnParams);
-        if (csk_diag_flag("CSK_GCN_V1") || p.stamps) {     // first form: two barriers per chunk, burst loads (A/B, stamps)
-            lds2 = (size_t)(R * KCG * MT + KCG * p.ldb) * sizeof(float);
-            k = big ? (R == 4 ? gcn_stage_sparse_kernel<128, true> : gcn_stage_sparse_kernel<128, false>)
-                    : (R == 4 ? gcn_stage_sparse_kernel<64, true> : gcn_stage_sparse_kernel<64, false>);
-        } else {                                           // ping-pong LDS, trickled loads, 3 workgroups / CU
-            lds2 = 2 * (size_t)(R * 8 * MT + 8 * p.ldb) * sizeof(float);
-            k = big ? (R == 4 ? gcn_stage_sparse2_kernel<128, true, 8> : gcn_stage_sparse2_kernel<128, false, 8>)
-                    : (R == 4 ? gcn_stage_sparse2_kernel<64, true, 8> : gcn_stage_sparse2_kernel<64, false, 8>);
-        }
+        // ping-pong LDS, trickled loads, 3 workgroups / CU
+        lds2 = 2 * (size_t)(R * 8 * MT + 8 * p.ldb) * sizeof(float);
+        k = big ? (R == 4 ? gcn_stage_sparse2_kernel<128, true, 8> : gcn_stage_sparse2_kernel<128, false, 8>)
+                : (R == 4 ? gcn_stage_sparse2_kernel<64, true, 8> : gcn_stage_sparse2_kernel<64, false, 8>);
         const int e = csk_ensure_lds((const void *)k, lds2);
         if (e) return e;
         hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds2, (hipStream_t)stream, p);
         return (int)hipGetLastError();
     }
+    // activation staging sweeps per row: whole frames of the tile only (no temporal halo), i.e. < NT + 2 V positions:
+    // <= 256 for 128-wide and <= 384 for 256-wide tiles at V <= 64 -- 3-4 / 5-6 sweeps of 64 lanes (all spill-free)
     const int nj = (p.ldb + 63) / 64;
-    if (nj > 14) CSK_FAIL("gcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
-    // activation staging sweeps per row: whole frames of the tile only (no temporal halo), i.e. <= 192 positions for
-    // 128-wide and <= 320 for 256-wide tiles at V <= 64 -- 3 / 5 sweeps; the 9 / 14-sweep forms remain as fall-backs
-    void (*kern)(GcnParams) =
-        big ? (nj <= 3 ? gcn_stage_kernel<128, 3> : nj <= 9 ? gcn_stage_kernel<128, 9> : gcn_stage_kernel<128, 14>)
-            : (nj <= 5 ? gcn_stage_kernel<64, 5> : nj <= 9 ? gcn_stage_kernel<64, 9> : gcn_stage_kernel<64, 14>);
+    if (nj > (big ? 4 : 6)) CSK_FAIL("gcn_stage: activation tile of %d positions per channel exceeds the staged maximum", p.ldb);
+    void (*kern)(GcnParams) = big ? (nj <= 3 ? gcn_stage_kernel<128, 3> : gcn_stage_kernel<128, 4>)
+                                  : (nj <= 5 ? gcn_stage_kernel<64, 5> : gcn_stage_kernel<64, 6>);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -194,6 +194,7 @@ struct BStage {
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 template <int NJ4>
 struct BStage4 {
+    static_assert(NJ4 <= 4, "issue_third covers sweeps 0..3 only: a fifth sweep would never be loaded (stale LDS rows)");
     static constexpr int RPW = KC / (NTHREADS / 64);   // rows per wave
     unsigned goff[NJ4];   // first position of the vector inside a channel row
     unsigned loff[NJ4];   // ... inside an LDS row

@@ -30,6 +30,9 @@ template <int NP, int NS>
 struct RingStage {
     static constexpr int N4 = NP / 4;
     static constexpr int RPU = NTHREADS / N4;                       // rows per sweep: 4 (NP=256) .. 16 (NP=64)
+    // window() makes a sweep's ring-slot offset wave-uniform with readfirstlane: legal only if a wave's rows of a sweep
+    // (64 / N4 of them) never straddle two slots, i.e. they divide the KC rows of a slot
+    static_assert(NP <= 256 && N4 <= 64 && KC % (64 / N4) == 0, "a wave's rows of a sweep must lie inside one ring slot");
     static constexpr int NB = (NS * KC + RPU - 1) / RPU;            // f32x4 per thread per chunk
     static constexpr int LDS_FLOATS = NB * RPU * NP;
     unsigned poff;                                                  // clamped position offset inside the tile

@@ -310,18 +310,20 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.fast_epi = (int64_t)p.Tres * V < (1ll << 27) && (int64_t)t_out * V < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
-    // the register staging holds <= 14 x 64 positions of an activation row; tiles whose input span (stride * frames
-    // + k taps) * V is longer than that (stride 3 with V > 32, ...) are narrowed: a tile then covers p.nt < NT output
-    // positions and the remaining MFMA columns idle.  Never the case for the ST-GCN shapes (V <= 25, stride <= 2).
+    // the register staging holds <= 9 (128-row tiles) / 14 (64-row tiles) x 64 positions of an activation row -- the
+    // widest spill-free instantiations; tiles whose input span (stride * frames + k taps) * V is longer than that
+    // (stride 3 with V > 32, ...) are narrowed: a tile then covers p.nt < NT output positions and the remaining MFMA
+    // columns idle.  Never the case for the ST-GCN shapes (V <= 25, stride <= 2).
+    const int nj_max = big ? 9 : 14;
     p.nt = NT;
     for (;;) {
         const int max_dt = (p.nt + V - 2) / V;
         p.ldb = round_up((stride * max_dt + k) * V, 4);
-        if ((p.ldb + 63) / 64 <= 14 || p.nt == 1) break;
+        if ((p.ldb + 63) / 64 <= nj_max || p.nt == 1) break;
         p.nt = p.nt > 16 ? p.nt - 16 : 1;
     }
     const int nj = (p.ldb + 63) / 64;
-    if (nj > 14) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (896)", p.ldb);
+    if (nj > nj_max) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (%d)", p.ldb, 64 * nj_max);
     const size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
     if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = t_out * V;
@@ -332,7 +334,7 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     // beyond it re-load and re-commit its last position: wasted load / LDS-write slots).  128x128 tiles of the
     // stride-1 layers need 6 sweeps, not 9: -2.7 % on their tiles.
     void (*kern)(TcnParams) =
-        big ? (nj <= 6 ? tcn_stage_kernel<128, 6> : nj <= 9 ? tcn_stage_kernel<128, 9> : tcn_stage_kernel<128, 14>)
+        big ? (nj <= 6 ? tcn_stage_kernel<128, 6> : tcn_stage_kernel<128, 9>)
             : (nj <= 6 ? tcn_stage_kernel<64, 6> : nj <= 9 ? tcn_stage_kernel<64, 9> : tcn_stage_kernel<64, 14>);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);

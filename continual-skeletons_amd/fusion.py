@@ -7,6 +7,7 @@ end-padding"); top-1/3/5 accuracies are reported.  Fusion and the per-sample ran
 one HIP kernel (``csk_fuse_rank_f32``); file I/O stays on the host.
 """
 import ctypes
+import io
 import pickle
 from pathlib import Path
 from typing import List, Sequence
@@ -17,11 +18,21 @@ import torch
 from . import native
 
 
-def load_labels(label_path) -> np.ndarray:
+class _LabelUnpickler(pickle.Unpickler):
+    """A label file holds lists / tuples of str and int only: nothing in it needs a global, so none is resolved (an
+    unrestricted ``pickle.load`` would run whatever callable a crafted file names; weights.py restricts its loader the
+    same way)."""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError(f"label files hold plain lists of names and integers; refusing to load {module}.{name}")
+
+
+def load_labels(label_path, trusted: bool = False) -> np.ndarray:
     """Targets of an NTU / Kinetics label file: a pickled ``(sample_names, labels)`` pair written by the reference's
-    dataset tooling under Python 2 (hence latin1), as read by multi_stream_eval.py:16-20 -> int64 array (N,)."""
+    dataset tooling under Python 2 (hence latin1), as read by multi_stream_eval.py:16-20 -> int64 array (N,).
+    ``trusted=True`` uses the unrestricted unpickler (label files that store numpy arrays)."""
     blob = Path(label_path).read_bytes()
-    pair = pickle.loads(blob, encoding="latin1")
+    pair = pickle.loads(blob, encoding="latin1") if trusted else _LabelUnpickler(io.BytesIO(blob), encoding="latin1").load()
     if not isinstance(pair, (tuple, list)) or len(pair) != 2:
         raise ValueError(f"{label_path}: expected a pickled (sample_names, labels) pair")
     return np.asarray(pair[1], dtype=np.int64)

@@ -35,7 +35,6 @@ SIGNATURES = {
     "csk_co_plan_update_weights": [_p, _i, _p, _p, _p, _p, _p],
     "csk_co_plan_reset": [_p],
     "csk_co_plan_counters": [_p, C.POINTER(C.c_int64), _i, _i],
-    "csk_co_plan_set_graphs": [_p, _i],
     "csk_co_plan_set_fusion": [_p, _i],
     "csk_co_plan_cycle": [_p, _p, _i, _p, _p, _p, _p, _p],
 }

@@ -111,3 +111,6 @@ class StreamShards:
 
     def state_bytes(self):
         return sum(m.state_bytes() for m in self.models)
+
+    def scratch_bytes(self):
+        return sum(m.scratch_bytes() for m in self.models)

@@ -13,8 +13,7 @@
  *    head entry points (csk_gcn_stage_f32 ... csk_fuse_rank_f32) neither allocate nor synchronise and are
  *    graph-capture safe (the first launch of a kernel instantiation raises its LDS cap with hipFuncSetAttribute).
  *    Exceptions: csk_stream_overlap_probe synchronises both streams it is given; csk_co_plan_create / _destroy
- *    allocate host memory; csk_co_plan_cycle with graphs enabled (csk_co_plan_set_graphs, experimental) runs the
- *    blocks on a stream owned by the plan, captures and instantiates hipGraphs, and fences with events.
+ *    allocate host memory.
  *  - packed weights are produced once on the host by continual-skeletons_amd/fold.py
  *    (BatchNorm(eval) + bias folding, zero padding of channel counts to CSK_CPAD / CSK_MT multiples).
  *  - return value: 0 = ok; <0 = argument error (see csk_last_error()); >0 = hipError_t of the launch.
@@ -262,12 +261,6 @@ void csk_co_plan_reset(csk_co_plan *plan);
  * n = 2 + 2*n_layers.  forward_step(x, update_state=False) (models/base.py:183-185) = read, cycle, write back: a
  * step only overwrites ring slots whose content is older than any window, so the counters are the whole state. */
 int csk_co_plan_counters(csk_co_plan *plan, int64_t *buf, int n, int set);
-/* latency mode: replay the block launches of a cycle from hipGraphs.  The launch sequence and all kernel arguments
- * of a cycle depend only on (r, per block: frames mod 16, emissions mod 16, warm-up state) -- 64 states in steady
- * per-frame stepping; a state runs eagerly on its first visit, is captured on the second and replayed from then on.
- * The blocks then run on a stream owned by the plan, fenced against the caller's stream by events; input
- * normalisation and the head stay ordinary launches.  Same kernels, same arguments: bit-identical results. */
-int csk_co_plan_set_graphs(csk_co_plan *plan, int enable);
 /* 1 (default): blocks that qualify advance a 4-frame cycle with one csk_co_block_step_f32 launch instead of a
  * csk_gcn_stage_f32 + csk_tcn_step_f32 pair (bit-identical results); 0: always the two-launch form. */
 int csk_co_plan_set_fusion(csk_co_plan *plan, int enable);

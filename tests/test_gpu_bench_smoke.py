@@ -20,10 +20,11 @@ def _run(*args):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("workload", ["clip", "step"])
+@pytest.mark.parametrize("workload", ["clip", "step", "both"])
 def test_bench_line_contract(workload):
     d = _run("--workload", workload, "--batch", "4", "--streams", "8", "--steps", "2", "--warmup", "1", "--step-cycles", "2",
-             "--stream-shards", "2", "--cpu-budget", "6")
+             "--stream-shards", "2", "--cpu-budget", "6", "--config4-batch", "2", "--config4-streams", "6",
+             "--cpu-budget-config4", "4")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -35,3 +36,13 @@ def test_bench_line_contract(workload):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    rc = d["roofline_config"]
+    assert rc["frac"] == rc["frac_executed"] and rc["frac_alg"] >= rc["frac"] and rc["flops_executed"] <= rc["flops_alg"]
+    assert d["ranks_seen"] == 1 and d["collective_backend"] is None
+    if workload == "both":        # BASELINE configs[3] legs carry their own whole-config roofline and CPU baseline
+        k = d["agcn_kinetics"]
+        for leg, unit in (("agcn_clip", "clips/s"), ("coagcn_online", "frames/s")):
+            assert k[leg]["value"] > 0 and k[leg]["unit"] == unit
+            assert k[leg]["roofline_config"]["bound"] == "mfma" and 0 < k[leg]["roofline_config"]["frac"] < 1
+            assert k[leg]["cpu_baseline"]["kind"] == "port" and k[leg]["cpu_baseline"]["value"] > 0
+        assert d["costgcn_online"]["roofline_config"]["frac"] > 0

@@ -6,7 +6,7 @@ import torch
 
 import _bootstrap
 from oracle import stgcn_oracle as o
-from tests.helpers import g6_state_dict, load_golden, max_err
+from tests.helpers import check_parity, g6_state_dict, load_golden, max_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -22,8 +22,8 @@ def test_co_temporal_convolution_pad_end():
     co.load_state_dict(sd, strict=True)
     co = co.to(DEV)
     x = torch.from_numpy(a["x"]).to(DEV)
-    assert max_err(co.forward(x).cpu(), a["y"]) <= TOL
-    assert max_err(co.forward_steps(x, pad_end=True).cpu(), a["y"]) <= TOL
+    check_parity(co.forward(x).cpu(), a["y"])
+    check_parity(co.forward_steps(x, pad_end=True).cpu(), a["y"])
 
 
 def _co_block(tag, padding=4):
@@ -41,29 +41,32 @@ def test_block_step_lags_clip_by_4(tag):
     outs = [blk.forward_step(x[:, :, i].contiguous()) for i in range(x.shape[2])]
     assert all(v is None for v in outs[:4])
     for t in range(x.shape[2] - 4):
-        assert max_err(outs[t + 4].cpu(), target[:, :, t]) <= TOL, t
+        check_parity(outs[t + 4].cpu(), target[:, :, t], note=t)
 
 
 @pytest.mark.parametrize("tag", ["convres", "strided", "ident", "nores"])
 def test_block_forward_and_forward_steps(tag):
     """tests/test_cost_gcn.py:179-271"""
     blk, x, target, s = _co_block(tag)
-    assert max_err(blk.forward(x).cpu(), target) <= TOL
+    check_parity(blk.forward(x).cpu(), target)
     o1 = blk.forward_steps(x, pad_end=False).cpu()
     cut = blk.delay // s
-    assert o1.shape[2] == target.shape[2] - cut and max_err(o1, target[:, :, : target.shape[2] - cut]) <= TOL
+    assert o1.shape[2] == target.shape[2] - cut
+    check_parity(o1, target[:, :, : target.shape[2] - cut])
     blk.clean_state()
     o2 = blk.forward_steps(x, pad_end=True).cpu()
-    assert o2.shape == target.shape and max_err(o2, target) <= TOL
+    assert o2.shape == target.shape
+    check_parity(o2, target)
 
 
 @pytest.mark.parametrize("tag", ["nopad", "nopad_strided"])
 def test_block_nopad(tag):
     """tests/test_st_gcn_mod.py:11-54 (padding=0: forward and stepping both give the un-padded clip output)"""
     blk, x, target, _ = _co_block(tag, padding=0)
-    assert max_err(blk.forward(x).cpu(), target) <= TOL
+    check_parity(blk.forward(x).cpu(), target)
     out = blk.forward_steps(x).cpu()
-    assert out.shape == target.shape and max_err(out, target) <= TOL
+    assert out.shape == target.shape
+    check_parity(out, target)
 
 
 def test_stack_of_three_blocks():
@@ -77,7 +80,8 @@ def test_stack_of_three_blocks():
         b = b.eval().to(DEV)
         h1 = b.forward(h1)
         h2 = b.forward_steps(h2, pad_end=True)
-    assert max_err(h1.cpu(), a["y"]) <= TOL and max_err(h2.cpu(), a["y"]) <= TOL
+    check_parity(h1.cpu(), a["y"], note="forward")
+    check_parity(h2.cpu(), a["y"], note="forward_steps pad_end")
 
 
 def test_clean_state_and_restart():
@@ -111,7 +115,7 @@ def test_costgcn_features_equal_clip_features_at_shifted_index():
             got.append(st.out[slot, :, : 2 * 25].view(256, 2, 25).permute(1, 0, 2).clone())
     assert len(got) == 7
     for j, g in enumerate(got):
-        assert max_err(g.cpu(), clip_feat[:, :, j].cpu()) <= TOL, j
+        check_parity(g.cpu(), clip_feat[:, :, j].cpu(), note=j)
 
 
 def test_costgcn_logits_vs_oracle_and_forward_modes():
@@ -133,7 +137,7 @@ def test_costgcn_logits_vs_oracle_and_forward_modes():
                 want.append(r)
     want = torch.stack(want, dim=2)
     assert got.shape == want.shape and got.shape[2] >= 5
-    assert max_err(got, want) <= TOL
+    check_parity(got, want)
     # default pool (75 / 19): after exactly T=300 frames one prediction exists and equals the clip-mode forward
     a, sd, x = g6_state_dict("ntu")
     co = pkg.CoStGcn(A).eval()
@@ -142,7 +146,38 @@ def test_costgcn_logits_vs_oracle_and_forward_modes():
     xd = x[:1].to(DEV)
     frame = co.forward(xd, forward_mode="frame").cpu()
     clip = co.forward(xd, forward_mode="clip").cpu()
-    assert frame.shape == (1, 60) and max_err(frame, clip) <= TOL
+    assert frame.shape == (1, 60)
+    check_parity(frame, clip)
+
+
+def test_costgcn_top3_equals_stgcn_default_init_default_pool():
+    """Mirror of the reference's one model-level pin, /root/reference/tests/test_cost_gcn.py:329-362: StGcn and CoStGcn
+    with the constructors' DEFAULT initialisation (gcn.bn.weight = 1e-6, base.py:257) and the DEFAULT pool (75 / 19),
+    weights transferred with ``co.load_state_dict(co.map_state_dict(reg.state_dict()))``; on a dummy_ntu sample
+    (torch.rand, datasets/datasets.py:301) the top-3 classes of ``reg(sample)``, ``co.forward(sample)`` and
+    ``co.forward_steps(sample)`` agree, and forward ~ forward_steps (rtol 1e-4)."""
+    torch.manual_seed(42)
+    reg = pkg.StGcn(A).eval()
+    co = pkg.CoStGcn(A).eval()
+    co.load_state_dict(co.map_state_dict(reg.state_dict()), strict=False)
+    assert (co.pool_size, co.pool_padding) == (75, 19)
+    reg, co = reg.to(DEV), co.to(DEV)
+    sample = torch.rand((1, 3, 300, 25, 2), generator=torch.Generator().manual_seed(0)).to(DEV)
+    target = reg(sample)
+    ks = 3
+    target_inds = torch.topk(target, ks).indices
+    o_co1 = co.forward(sample)
+    assert torch.equal(target_inds, torch.topk(o_co1, ks).indices)
+    o_co2 = co.forward_steps(sample)
+    assert o_co2.shape == (1, 60, 1)               # T = 300 frames -> exactly one prediction with the default pool
+    o_co2 = o_co2.squeeze(-1)                      # the reference's trailing ``squeeze`` module (base.py:99-101)
+    assert torch.equal(target_inds, torch.topk(o_co2, ks).indices)
+    assert torch.allclose(o_co1, o_co2, rtol=1e-4)
+    check_parity(o_co2.cpu(), o_co1.cpu(), ref_cap=32.0, note="forward_steps vs forward, default init / pool")
+    # and the oracle agrees with all three on the same weights
+    sd = {k: v.cpu() for k, v in reg.state_dict().items()}
+    with torch.no_grad():
+        check_parity(target.cpu(), o.stgcn_forward(sample.cpu(), sd), ref_cap=32.0, note="StGcn default init vs oracle")
 
 
 @pytest.mark.parametrize("native_plan", [True, False])
@@ -162,7 +197,7 @@ def test_model_forward_steps_pad_end(native_plan):
     peek = co.forward_steps(x.to(DEV), pad_end=True, update_state=False).cpu()
     got = co.forward_steps(x.to(DEV), pad_end=True).cpu()
     assert got.shape == want.shape == (1, 60, 15)
-    assert max_err(got, want) <= TOL
+    check_parity(got, want)
     assert torch.equal(peek, got)                                        # the peek ran from the same (clean) state
 
 
@@ -248,11 +283,13 @@ def test_blocks_accept_a_foreign_graph_conv_module(ci, co, stride):
     with torch.no_grad():
         want = o.st_block(x, sd, "", stride, True, gcn=_foreign_gcn_oracle)
     got = blk.to(DEV)(x.to(DEV)).cpu()
-    assert got.shape == want.shape and max_err(got, want) <= TOL
+    assert got.shape == want.shape
+    check_parity(got, want)
     co_blk = pkg.CoSpatioTemporalBlock(ci, co, A, stride=stride, padding=4, CoGraphConv=_ForeignGraphConv).eval()
     co_blk.load_state_dict(sd, strict=True)
     steps = co_blk.to(DEV).forward_steps(x.to(DEV), pad_end=True).cpu()
-    assert steps.shape == want.shape and max_err(steps, want) <= TOL
+    assert steps.shape == want.shape
+    check_parity(steps, want)
 
 
 def test_update_state_false_peeks_without_advancing():
@@ -314,37 +351,37 @@ def test_latency_mode_split_k_matches_oracle_and_default(native_plan):
     the default path up to fp32 summation order; per-frame stepping and 4-frame cycles stay bitwise equal to each
     other; a slab that fills the GPU is left on the default path (bitwise equal to it)."""
     a, sd, x = g6_state_dict("ntu")
-    T = 280                                        # per-frame stepping visits each of its 64 launch states 4 times:
-    x = x[:2, :, :T].to(DEV)                       # eager, captured, then replayed from the hipGraph
+    T = 160
+    x = x[:2, :, :T].to(DEV)
     nets = {}
-    for mode in ("default", "latency", "latency_eager", "latency_cycles"):
+    for mode in ("default", "latency", "latency_cycles"):
         co = pkg.CoStGcn(A, pool_size=4, pool_padding=1).eval()
         co.use_native_plan = native_plan
         co.load_state_dict(sd, strict=True)
         co = co.to(DEV)
         if mode != "default":
-            co.set_latency_mode(8, graphs=mode != "latency_eager")      # graph replay is opt-in (slower than eager here)
+            co.set_latency_mode(8)
         nets[mode] = co
     outs = {m: [] for m in nets}
     for t in range(T):
         f = x[:, :, t].contiguous()
-        for m in ("default", "latency", "latency_eager"):
+        for m in ("default", "latency"):
             r = nets[m].forward_step(f)
             if r is not None:
                 outs[m].append(r)
     for t in range(0, T, 4):
         outs["latency_cycles"] += nets["latency_cycles"].forward_cycle([x[:, :, t + f].contiguous() for f in range(4)])
-    assert len(outs["default"]) == len(outs["latency"]) == len(outs["latency_eager"]) == len(outs["latency_cycles"]) >= 40
+    assert len(outs["default"]) == len(outs["latency"]) == len(outs["latency_cycles"]) >= 18
     # default: the 256-channel blocks always split their K loop in 3 (slab-size independent), nothing else is split
     assert [nets["default"].layers[f"layer{i + 1}"]._state.ksplit for i in range(10)] == [1] * 7 + [3] * 3
     assert nets["latency"].layers["layer9"]._state.ksplit > 3 and nets["latency"].layers["layer2"]._state.ksplit > 1
-    for d, l, e, c in zip(outs["default"], outs["latency"], outs["latency_eager"], outs["latency_cycles"]):
-        assert max_err(l.cpu(), d.cpu()) <= TOL * max(1.0, float(d.abs().max()))
-        assert torch.equal(l, e) and torch.equal(l, c)          # graph replay / cycles: bit-identical to eager stepping
+    for d, l, c in zip(outs["default"], outs["latency"], outs["latency_cycles"]):
+        check_parity(l.cpu(), d.cpu(), note="latency mode vs default (summation order)")
+        assert torch.equal(l, c)                                # 4-frame cycles: bit-identical to per-frame stepping
     orc = o.CoStGcnOracle(sd, pool_size=4, pool_padding=1)
     want = [r for r in (orc.forward_step(x[:, :, t].cpu()) for t in range(120)) if r is not None]
     for l, w in zip(outs["latency"], want):
-        assert max_err(l.cpu(), w) <= TOL * max(1.0, float(w.abs().max()))
+        check_parity(l.cpu(), w, note="latency mode vs oracle")
     # a full slab: latency mode must not change a bit
     big = [pkg.CoStGcn(A, pool_size=2, pool_padding=0).eval() for _ in range(2)]
     for b in big:

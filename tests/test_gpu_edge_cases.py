@@ -5,7 +5,7 @@ import torch
 
 import _bootstrap
 from oracle import stgcn_oracle as o
-from tests.helpers import max_err
+from tests.helpers import BLOCK_OUT_KEYS, check_parity, max_err, unit_scale_
 
 pytestmark = pytest.mark.gpu
 pkg = _bootstrap.load()
@@ -44,11 +44,9 @@ def _rand_block(ci, co, stride, res, v, seed, padding=-1):
 def test_block_edge_shapes(ci, co, stride, res, T, N, v):
     m, sd = _rand_block(ci, co, stride, res, v, seed=ci * 7 + T)
     x = torch.rand(N, ci, T, v, generator=torch.Generator().manual_seed(T))
-    with torch.no_grad():
-        want = o.st_block(x, sd, "", stride, res)
+    want = unit_scale_(m, sd, lambda s: o.st_block(x, s, "", stride, res), BLOCK_OUT_KEYS)
     got = m.to(DEV)(x.to(DEV)).cpu()
-    assert got.shape == want.shape
-    assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max()))
+    check_parity(got, want, shape=(ci, co, stride, res, T, N, v))
 
 
 @pytest.mark.parametrize("T,pad", [(9, 0), (10, 0), (12, 2)])
@@ -59,7 +57,8 @@ def test_unpadded_block_minimal_lengths(T, pad):
     with torch.no_grad():
         want = o.st_block(x, sd, "", 1, True, pad)
     got = m.to(DEV)(x.to(DEV)).cpu()
-    assert got.shape == want.shape == (2, 4, T + 2 * pad - 8, 25) and max_err(got, want) <= TOL
+    assert got.shape == want.shape == (2, 4, T + 2 * pad - 8, 25)
+    check_parity(got, want)
 
 
 def test_too_short_clip_is_an_error():
@@ -84,7 +83,8 @@ def test_continual_block_odd_stream_counts(n_streams, v):
     with torch.no_grad():
         want = o.st_block(x, sd, "", 1, True)
     got = co.forward_steps(x.to(DEV), pad_end=True).cpu()
-    assert got.shape == want.shape and max_err(got, want) <= TOL
+    assert got.shape == want.shape
+    check_parity(got, want)
 
 
 def test_stream_shards_get_concurrent_hardware_queues():
@@ -140,11 +140,9 @@ def test_block_random_sweep(seed):
                 buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
     sd = {k: t.clone() for k, t in m.state_dict().items()}
     x = torch.rand(N, ci, T, v, generator=g)
-    with torch.no_grad():
-        want = o.st_block(x, sd, "", stride, res)
+    want = unit_scale_(m, sd, lambda s: o.st_block(x, s, "", stride, res), BLOCK_OUT_KEYS)
     got = m.to(DEV)(x.to(DEV)).cpu()
-    assert got.shape == want.shape, (ci, co, stride, res, T, N, v)
-    assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max())), (ci, co, stride, res, T, N, v)
+    check_parity(got, want, shape=(ci, co, stride, res, T, N, v))
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -173,13 +171,11 @@ def test_continual_block_random_sweep(seed):
                 buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
     sd = {k: t.clone() for k, t in ref.state_dict().items()}
     x = torch.rand(N, ci, T, v, generator=g)
-    with torch.no_grad():
-        want = o.st_block(x, sd, "", stride, res)
+    want = unit_scale_(ref, sd, lambda s: o.st_block(x, s, "", stride, res), BLOCK_OUT_KEYS)
     blk = pkg.CoSpatioTemporalBlock(ci, co, A, stride=stride, residual=res, padding=4).eval()
     blk.load_state_dict(sd, strict=True)
     got = blk.to(DEV).forward_steps(x.to(DEV), pad_end=True).cpu()
-    assert got.shape == want.shape, (ci, co, stride, res, T, N, v)
-    assert max_err(got, want) <= TOL * max(1.0, float(want.abs().max())), (ci, co, stride, res, T, N, v)
+    check_parity(got, want, shape=(ci, co, stride, res, T, N, v))
 
 
 def test_nan_propagates_through_relu_epilogues():

@@ -9,7 +9,7 @@ import torch
 
 import _bootstrap
 from oracle import stgcn_oracle as o
-from tests.helpers import g6_state_dict, max_err
+from tests.helpers import check_parity, g6_state_dict, randomise_unit_
 
 pytestmark = pytest.mark.gpu
 pkg = _bootstrap.load()
@@ -31,7 +31,7 @@ def test_config2_batch256_clip_forward():
     idx = [0, 1, 37, 100, 128, 200, 254, 255]
     with torch.no_grad():
         want = o.stgcn_forward(x[idx].cpu(), sd)
-    assert max_err(full[idx].cpu(), want) <= TOL
+    check_parity(full[idx].cpu(), want)
     for lo in range(0, 256, 64):                                  # batch invariance, bitwise
         part = net(x[lo:lo + 64].contiguous())
         assert torch.equal(part, full[lo:lo + 64])
@@ -65,7 +65,7 @@ def test_config3_1024_streams_online():
                 want.append(r)
     assert len(want) == len(got)
     for gv, wv in zip(got, want):
-        assert max_err(gv[pick].cpu(), wv) <= TOL
+        check_parity(gv[pick].cpu(), wv)
     small = pkg.CoStGcn(A, pool_size=3, pool_padding=1).eval()
     small.load_state_dict(sd, strict=True)
     small = small.to(DEV)
@@ -77,20 +77,7 @@ def test_config3_1024_streams_online():
 
 
 def _randomise_agcn(m, seed):
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for name, prm in m.named_parameters():
-            if name.endswith("graph_attn") or ("bn" in name and name.endswith("weight")):
-                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
-            elif name.endswith("bias"):
-                prm.copy_(torch.rand(prm.shape, generator=g) - 0.5)
-            elif "a_conv" in name or "b_conv" in name:
-                prm.copy_(torch.randn(prm.shape, generator=g) * 0.5)       # a non-uniform attention
-        for name, buf in m.named_buffers():
-            if name.endswith("running_var"):
-                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
-            elif name.endswith("running_mean"):
-                buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
+    randomise_unit_(m, seed, attn_scale=1 / 18)        # O(1) activations through all ten blocks, non-uniform attention
 
 
 def test_config4_agcn_clip_batch64_kinetics_shape():
@@ -108,7 +95,7 @@ def test_config4_agcn_clip_batch64_kinetics_shape():
     idx = [0, 63]
     with torch.no_grad():
         want = o.stgcn_forward(x[idx].cpu(), sd, gcn=o.adaptive_graph_conv)
-    assert max_err(full[idx].cpu(), want) <= TOL * max(1.0, float(want.abs().max()))
+    check_parity(full[idx].cpu(), want)
     for lo in range(0, 64, 16):
         assert torch.equal(net(x[lo:lo + 16].contiguous()), full[lo:lo + 16])
 
@@ -146,7 +133,7 @@ def test_config4_coagcn_1024_streams_kinetics_shape():
                 want.append(r)
     assert len(want) == len(got)
     for gv, wv in zip(got, want):
-        assert max_err(gv[pick].cpu(), wv) <= TOL * max(1.0, float(wv.abs().max()))
+        check_parity(gv[pick].cpu(), wv)
     small = make()
     small.load_state_dict(big.state_dict(), strict=True)       # make() draws fresh conv weights
     small = small.to(DEV)

@@ -99,12 +99,93 @@ def test_bench_two_ranks_toy_sizes():
     env = dict(os.environ, CSK_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "3", "--streams", "6",
-           "--steps", "2", "--warmup", "1", "--step-cycles", "2", "--stream-shards", "2", "--no-cpu-baseline"]
+           "--steps", "2", "--warmup", "1", "--step-cycles", "2", "--stream-shards", "2", "--no-cpu-baseline",
+           "--config5-batch", "4"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 6
+    # the configs[4] leg (1024 clips / GPU in a real run) beside the weak-scaling headline; two gloo ranks SHARE the GPU here
+    assert d["config5"]["clips_per_gpu"] == 4 and d["config5"]["global_batch"] == 8 and d["config5"]["value"] > 0
+    assert d["ranks_seen"] == 1 and d["collective_backend"] == "gloo"
     assert d["value"] > 0 and d["costgcn_online"]["value"] > 0 and d["costgcn_online"]["streams_per_gpu"] == 6
     assert "agcn_kinetics" not in d          # the config-4 side numbers are per GPU, reported at N = 1 only
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["CSK_ROOT"])
+import torch, torch.distributed as dist
+import _bootstrap, bench
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+pkg = _bootstrap.load()
+from continual_skeletons_amd import parallel
+net = pkg.StGcn(pkg.ntu_graph().A, input_shape=(3, 40, 25, 2), num_classes=60).eval()
+bench.randomise_(net, seed=0)
+net = net.to(dev)
+x = torch.rand((5, 3, 40, 25, 2), generator=torch.Generator().manual_seed(11)).to(dev)
+ok = True
+for it in range(3):                       # stream ordering: the collective follows the kernels that produce its input
+    logits = net(x)
+    g1 = parallel.all_gather_logits(logits)
+    g2 = parallel.all_gather_ragged(logits, 5)
+    torch.cuda.synchronize()
+    ok = ok and torch.equal(g1, logits) and torch.equal(g2, logits) and bool(torch.isfinite(g1).all())
+# the side stream of a StreamShards engine next to RCCL's own streams (hardware-queue probe, parallel.concurrent_streams)
+def make():
+    co = pkg.CoStGcn(pkg.ntu_graph().A, pool_size=3, pool_padding=1).eval()
+    bench.randomise_(co, seed=0)
+    return co.to(dev)
+eng = parallel.StreamShards(make, 6, 2, dev)
+frames = torch.rand((92, 6, 3, 25, 2), generator=torch.Generator().manual_seed(12)).to(dev)
+seen = 0
+for c in range(23):
+    out = eng.forward_cycle([frames[4 * c + f] for f in range(4)])
+    if out is not None:
+        g = parallel.all_gather_logits(out)
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(g, out)
+        seen += 1
+t = torch.tensor([1.0], device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+print(f"RCCL backend={dist.get_backend()} ok={ok} seen={seen} allreduce={float(t.item())}", flush=True)
+dist.destroy_process_group()
+sys.exit(0 if (ok and seen > 0) else 1)
+'''
+
+
+def test_rccl_world_size_1_all_gather_on_the_gpu(tmp_path):
+    """As close to RCCL as one GPU allows: a real ``backend="nccl"`` (= RCCL) process group of world size 1 bound to cuda:0
+    (library load, communicator init with ``device_id``, stream ordering between our HIP launches and the collective,
+    the probed shard streams beside RCCL's own): real logits through parallel.all_gather_logits / all_gather_ragged and
+    the all_reduce + barrier bench.py uses.  The 8-rank exchange itself can only run on the driver's 8-GPU node."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), CSK_ROOT=ROOT, RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, f"{out.stdout[-1000:]} {out.stderr[-3000:]}"
+    assert "RCCL backend=nccl ok=True" in out.stdout
+
+
+def test_bench_one_rank_rccl_toy_sizes():
+    """bench.py --gpus 1 under torch.distributed.run with the default backend: WORLD_SIZE = 1 takes the single-process
+    path; with CSK_BENCH_FORCE_DIST=1 it initialises RCCL anyway and runs every collective of the N > 1 path (barrier,
+    max-over-ranks all_reduce, logit all-gather, config5 leg) on one rank."""
+    env = dict(os.environ, CSK_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "3", "--streams", "6",
+           "--steps", "2", "--warmup", "1", "--step-cycles", "2", "--stream-shards", "2", "--no-cpu-baseline",
+           "--config5-batch", "4"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["ranks_seen"] == 1 and d["collective_backend"] == "nccl"
+    assert d["config5"]["clips_per_gpu"] == 4 and d["config5"]["value"] > 0

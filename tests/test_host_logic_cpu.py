@@ -214,6 +214,14 @@ def test_fusion_file_loaders(tmp_path):
     (tmp_path / "l.pkl").write_bytes(pickle.dumps((["a", "b", "c"], [4, 0, 2]), protocol=2))
     assert fusion.load_preds(tmp_path / "p.npy").shape == (3, 5)
     assert fusion.load_labels(tmp_path / "l.pkl").tolist() == [4, 0, 2]
+    # a label file is plain lists of str / int: anything that needs a global (here: os.system) is refused, not executed
+    (tmp_path / "evil.pkl").write_bytes(b"cos\nsystem\n(S'true'\ntR.")
+    with pytest.raises(pickle.UnpicklingError, match="refusing"):
+        fusion.load_labels(tmp_path / "evil.pkl")
+    (tmp_path / "np.pkl").write_bytes(pickle.dumps((["a"], np.array([3])), protocol=2))
+    with pytest.raises(pickle.UnpicklingError):
+        fusion.load_labels(tmp_path / "np.pkl")
+    assert fusion.load_labels(tmp_path / "np.pkl", trusted=True).tolist() == [3]
     with pytest.raises(ValueError):
         fusion.load_preds(tmp_path / "bad.npy")
     with pytest.raises(ValueError):
@@ -239,3 +247,18 @@ def test_co_block_step_argument_errors_are_reported_without_a_gpu():
                            (dict(cnt_=(C.c_int32 * 3)(2, 1, 4)), "skeleton-sparse"), (dict(V=43, P=344), "longer than 128")]:
         assert call(**kwargs) < 0
         assert needle in lib.csk_last_error().decode(), (kwargs, lib.csk_last_error().decode())
+
+
+def test_no_kernel_spills():
+    """Every kernel instantiation a public entry point can select is spill-free: the compiler's resource report, which
+    build.sh keeps next to the library, shows 0 bytes of scratch per lane for each of them (a spilling instantiation is a
+    2x performance cliff for the shapes that select it)."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(pkg.native.LIB_PATH), "kernel_resources.txt")
+    assert os.path.exists(path), "build with continual-skeletons_amd/csrc/build.sh (it writes kernel_resources.txt)"
+    text = open(path).read()
+    kernels = re.findall(r"Name: (\S+)\n(?:.*\n)*?ScratchSize \[bytes/lane\]: (\d+)", text)
+    assert len(kernels) >= 30, len(kernels)
+    spilling = [(n, int(b)) for n, b in kernels if int(b) != 0]
+    assert not spilling, spilling

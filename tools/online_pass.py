@@ -24,6 +24,7 @@ ap.add_argument("--warm-cycles", type=int, default=0, help="default: enough to f
 ap.add_argument("--no-fuse", action="store_true", help="two launches per block everywhere (no csk_co_block_step_f32)")
 ap.add_argument("--force-ksplit", type=int, default=0, help="split-K factor forced on blocks with C_out >= --ksplit-min-c (experiment)")
 ap.add_argument("--ksplit-min-c", type=int, default=256)
+ap.add_argument("--model", default="costgcn", choices=["costgcn", "coagcn"], help="coagcn: BASELINE configs[3], Kinetics-400 shape (V = 18)")
 args = ap.parse_args()
 
 pkg = _bootstrap.load()
@@ -32,9 +33,16 @@ from continual_skeletons_amd import parallel  # noqa: E402
 dev = torch.device("cuda:0")
 
 
+V = 18 if args.model == "coagcn" else 25
+
+
 def make():
-    net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
-    bench.randomise_(net, seed=0)
+    if args.model == "coagcn":
+        net = pkg.CoAGcn(pkg.kinetics_graph().A, bench.KIN_SHAPE, 400).eval()
+        bench.randomise_(net, seed=0, attn_scale=1 / 18)
+    else:
+        net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+        bench.randomise_(net, seed=0)
     if args.force_ksplit > 1:
         for blk in net.layers.values():
             if blk.out_channels >= args.ksplit_min_c:
@@ -46,7 +54,7 @@ def make():
 
 
 eng = parallel.StreamShards(make, args.streams, args.shards, dev)
-frames = torch.rand((8, args.streams, 3, 25, 2), device=dev, generator=torch.Generator(device=dev).manual_seed(200))
+frames = torch.rand((8, args.streams, 3, V, 2), device=dev, generator=torch.Generator(device=dev).manual_seed(200))
 warm = args.warm_cycles or (76 + 4 * 56 + args.fpl - 1) // args.fpl + 2
 fi = 0
 
@@ -67,5 +75,5 @@ for _ in range(args.cycles):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 assert out is not None and bool(torch.isfinite(out).all())
-print(f"ONLINE_PASS fused={not args.no_fuse} shards={args.shards} fpl={args.fpl} streams={args.streams} warm_cycles={warm} cycles={args.cycles} "
+print(f"ONLINE_PASS model={args.model} fused={not args.no_fuse} shards={args.shards} fpl={args.fpl} streams={args.streams} warm_cycles={warm} cycles={args.cycles} "
       f"ms_per_cycle={dt / args.cycles * 1e3:.4f} frames_per_s={args.fpl * args.streams * args.cycles / dt:.0f}")

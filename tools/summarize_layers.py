@@ -24,7 +24,8 @@ import workmodel as wm  # noqa: E402
 
 def short(name):
     for k in ("gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
-              "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel"):
+              "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
+              "agcn_attention_kernel", "tcn_split_stage_kernel", "tcn_split_step_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
             return k + t
@@ -32,6 +33,8 @@ def short(name):
 
 
 def klass(name):
+    if "agcn_attention" in name:
+        return "a"
     if "gcn_stage" in name:
         return "g"
     if "tcn_step" in name or "tcn_stage" in name:
@@ -54,7 +57,13 @@ def main():
     ap.add_argument("--note", default="")
     ap.add_argument("--mode", default="online", choices=["online", "clip"])
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--model", default="stgcn", choices=["stgcn", "agcn"],
+                    help="agcn: A-GCN / CoAGCN at the Kinetics shape (V = 18): per block embedding conv (a tcn kernel with "
+                         "k = 1 in front of the graph conv), attention, general graph conv, temporal conv")
     a = ap.parse_args()
+    V = 18 if a.model == "agcn" else 25
+    adaptive = a.model == "agcn"
+    tcn_per_cycle = 20 if adaptive else 10
     files = sorted(glob.glob(os.path.join(a.trace_dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if not files:
         raise SystemExit(f"no kernel_trace.csv under {a.trace_dir}")
@@ -67,10 +76,10 @@ def main():
     clip = a.mode == "clip"
     if clip:
         n_skel = a.batch * 2
-        layers = [dict(l, frames_in=l["t_in"], emissions=l["t_out"]) for l in wm.clip_layers()]
+        layers = [dict(l, frames_in=l["t_in"], emissions=l["t_out"]) for l in wm.clip_layers(V=V, adaptive=adaptive)]
     else:
         n_skel = a.streams // a.shards * 2
-        layers = wm.step_layers(a.fpl)
+        layers = wm.step_layers(a.fpl, V=V, adaptive=adaptive)
     per_layer = [collections.defaultdict(list) for _ in range(10)]          # stage -> [ms]
     per_kernel = collections.defaultdict(list)
     cyc_kernel_ms, windows, other_ms = [], [], []
@@ -86,7 +95,7 @@ def main():
             prev_i = k == "i"
             if cur is not None:
                 cur.append(r)
-        good = [c for c in cycles if sum(klass(r["Kernel_Name"]) in "tf" for r in c) == 10]
+        good = [c for c in cycles if sum(klass(r["Kernel_Name"]) in "tf" for r in c) == tcn_per_cycle]
         if len(good) < a.cycles:
             continue
         used_streams += 1
@@ -97,12 +106,19 @@ def main():
             k in r["Kernel_Name"] for k in ("co_spatial_pool", "co_window_mean", "fc_kernel", "pool_kernel"))]
         windows.append((int(good[0][0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in path)))
         for c in good:
-            li, tot, oth = 0, 0.0, 0.0
+            li, tot, oth, seen_g = 0, 0.0, 0.0, False
             for r in c:
                 ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
                 k = klass(r["Kernel_Name"])
                 tot += ms
                 per_kernel[short(r["Kernel_Name"])].append(ms)
+                if adaptive and li < 10 and (k == "a" or (k == "t" and not seen_g)):
+                    per_layer[li]["e" if k == "t" else "a"].append(ms)       # embedding conv / attention of block li
+                    continue
+                if k == "g":
+                    seen_g = True
+                elif k in "tf":
+                    seen_g = False
                 if k in "gtf" and li < 10:
                     per_layer[li][k].append(ms)
                     if k in "tf":
@@ -115,13 +131,15 @@ def main():
         raise SystemExit("no stream with enough steady-state cycles found")
     w0, w1 = min(w[0] for w in windows), max(w[1] for w in windows)
     wall_ms = (w1 - w0) / 1e6 / a.cycles
-    fa, fe, by = wm.clip_totals(a.batch * 2) if clip else wm.step_totals(a.streams * 2, a.fpl)
+    fa, fe, by = (wm.clip_totals(a.batch * 2, V=V, adaptive=adaptive) if clip else
+                  wm.step_totals(a.streams * 2, a.fpl, V=V, adaptive=adaptive))
     peak = wm.PEAK_F32_MFMA_TFLOPS
 
     if clip:
-        L = [f"# Clip path, rocprofv3 --kernel-trace ({a.tag}): bench.py --workload clip --batch {a.batch}; last {a.cycles} forwards", ""]
+        L = [f"# Clip path, rocprofv3 --kernel-trace ({a.tag}): " + (f"tools/agcn_prof.py {a.batch} (A-GCN, Kinetics shape)" if adaptive else
+             f"bench.py --workload clip --batch {a.batch}") + f"; last {a.cycles} forwards", ""]
     else:
-        L = [f"# Online path, rocprofv3 --kernel-trace ({a.tag}): tools/online_pass.py --shards {a.shards} --fpl {a.fpl} "
+        L = [f"# Online path, rocprofv3 --kernel-trace ({a.tag}): tools/online_pass.py " + ("--model coagcn " if adaptive else "") + f"--shards {a.shards} --fpl {a.fpl} "
              f"--streams {a.streams}; last {a.cycles} steady-state cycles of {used_streams} HIP stream(s)", ""]
     if a.note:
         L += [a.note, ""]
@@ -136,12 +154,19 @@ def main():
     csv_rows = []
     sums = dict(g=[0.0, 0.0], t=[0.0, 0.0])
     for i, (pl, lw) in enumerate(zip(per_layer, layers)):
-        for k in "gtf":
+        for k in "eagtf":
             if not pl[k]:
                 continue
             avg = sum(pl[k]) / len(pl[k])
-            if k == "g":
-                alg, ex, cnt = lw["gcn_macs"] + lw["agg_dense"], lw["gcn_macs"] + lw["agg_sparse"], lw["frames_in"]
+            if k == "e":
+                alg = ex = lw["embed_macs"]
+                cnt = lw["frames_in"]
+            elif k == "a":
+                alg = ex = lw["attn_macs"]
+                cnt = lw["frames_in"]
+            elif k == "g":
+                base = lw["gcn_macs"] - lw.get("embed_macs", 0) - lw.get("attn_macs", 0)
+                alg, ex, cnt = base + lw["agg_dense"], base + lw["agg_sparse"], lw["frames_in"]
             elif k == "t":
                 alg = ex = lw["tcn_macs"]
                 cnt = lw["emissions"]
@@ -150,18 +175,18 @@ def main():
                 cnt = lw["emissions"]
             alg, ex = 2e-9 * alg * n_skel, 2e-9 * ex * n_skel
             tf = alg / avg
-            name = {"g": "gcn", "t": "tcn_stage" if clip else "tcn_step", "f": "fused"}[k]
+            name = {"e": "embed 1x1", "a": "attention", "g": "gcn", "t": "tcn_stage" if clip else "tcn_step", "f": "fused"}[k]
             L.append(f"| L{i + 1} {lw['ci']}->{lw['co']} s{lw['stride']} | {name} | {cnt} | {len(pl[k])} | {avg:.4f} | {alg:.2f} ({ex:.2f}) | {tf:.1f} | {tf / peak:.3f} | {ex / avg:.1f} | {ex / avg / peak:.3f} |")
             csv_rows.append(dict(layer=i + 1, c_in=lw["ci"], c_out=lw["co"], stride=lw["stride"], stage=name, launches=len(pl[k]),
                                  avg_ms=round(avg, 5), gflop_alg=round(alg, 3), gflop_exec=round(ex, 3), tflops_alg=round(tf, 2),
                                  frac=round(tf / peak, 4), tflops_exec=round(ex / avg, 2), frac_exec=round(ex / avg / peak, 4)))
-            kk = "g" if k == "g" else "t"
+            kk = "g" if k in "eag" else "t"
             sums[kk][0] += avg
             sums[kk][1] += alg
     ksum = sum(cyc_kernel_ms) / len(cyc_kernel_ms)
     L += ["", "## Whole cycle", "",
           f"* kernel time per cycle and stream (sum of durations): {ksum:.4f} ms, of which non-block kernels (input norm, head, copies) {sum(other_ms) / len(other_ms):.4f} ms",
-          f"* GCN-stage launches: {sums['g'][0]:.4f} ms for {sums['g'][1]:.1f} GFLOP -> {sums['g'][1] / max(sums['g'][0], 1e-9):.1f} TFLOP/s ({sums['g'][1] / max(sums['g'][0], 1e-9) / peak:.3f})"
+          f"* GCN-stage launches (embedding + attention + graph conv for A-GCN): {sums['g'][0]:.4f} ms for {sums['g'][1]:.1f} GFLOP -> {sums['g'][1] / max(sums['g'][0], 1e-9):.1f} TFLOP/s ({sums['g'][1] / max(sums['g'][0], 1e-9) / peak:.3f})"
           if sums["g"][0] else "* no separate GCN-stage launches",
           f"* TCN-step / fused launches: {sums['t'][0]:.4f} ms for {sums['t'][1]:.1f} GFLOP -> {sums['t'][1] / sums['t'][0]:.1f} TFLOP/s ({sums['t'][1] / sums['t'][0] / peak:.3f})",
           f"* wall time per cycle over all streams (first start to last end of the window / {a.cycles}): {wall_ms:.4f} ms "
