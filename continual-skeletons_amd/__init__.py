@@ -15,6 +15,7 @@ from .blocks import (  # noqa: F401
     SpatioTemporalBlock,
     TemporalConvolution,
     init_weights,
+    set_precision,
     unity,
     zero,
 )
@@ -39,5 +40,5 @@ __all__ = [
     "SpatioTemporalBlock", "SpatialGraphConv", "StGcnBlock", "CoStGcnBlock", "StGcn", "CoStGcn",
     "CoGraphConvolution", "CoTemporalConvolution", "CoSpatioTemporalBlock",
     "AdaptiveGraphConvolution", "CoAdaptiveGraphConvolution", "AGcn", "CoAGcn", "init_weights", "zero", "unity",
-    "native", "fusion",
+    "native", "fusion", "set_precision",
 ]

@@ -71,6 +71,37 @@ class _Folded(nn.Module):
             )
 
 
+PRECISIONS = ("f32", "bf16x3")
+
+
+def set_precision(module: nn.Module, precision: str = "f32") -> nn.Module:
+    """Select the arithmetic of the temporal-conv kernels of ``module`` and every block below it.
+
+    "f32" (default): exact fp32 (v_mfma_f32_32x32x2_f32) -- bit for bit an fmaf chain, the reference's own arithmetic.
+    "bf16x3" (opt-in): fp32-GRADE -- every operand split into three bf16 pieces, six piece products per fp32 product on
+    the bf16 matrix pipe, fp32 accumulation (csrc/tcn_split.hip).  Results differ from "f32" by a few 1e-6 on O(1)
+    activations (tests/test_gpu_precision_modes.py records the measured error); it is never reported as fp32.  Applies
+    to the 9 x 1 temporal conv + 1 x 1 residual conv of SpatioTemporalBlock / CoSpatioTemporalBlock (70 % of the FLOPs);
+    the graph conv stays exact fp32."""
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+    hit = 0
+    for m in module.modules():
+        if isinstance(m, SpatioTemporalBlock):
+            if precision != "f32" and not (m._native_tail and m.tcn.kernel_size == 9):
+                raise NotImplementedError("bf16x3 is built for blocks with the native 9 x 1 temporal conv")
+            m.precision = precision
+            m.refold()
+            hit += 1
+    if not hit:
+        raise ValueError("no SpatioTemporalBlock below this module: nothing to set")
+    for m in module.modules():
+        hook = getattr(m, "_precision_changed", None)
+        if hook is not None:
+            hook()
+    return module
+
+
 def _check_input(x, channels, name):
     native.require_device_f32(x, name)
     if x.dim() != 4 or x.shape[1] != channels:
@@ -159,7 +190,9 @@ class TemporalConvolution(_Folded):
         return tcn_stage(x, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.padding, relu=False)
 
 
-def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=None, w_res=None, res_off=0, out=None):
+def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=None, w_res=None, res_off=0, out=None,
+              split=False):
+    """csk_tcn_stage_f32, or with split=True csk_tcn_stage_bf16x3 (w / w_res are then the split operand images)."""
     n, c, t_in, v = y.shape
     if t_in + 2 * pad < k:
         raise RuntimeError(f"temporal extent {t_in} (+2*{pad}) shorter than kernel {k}")
@@ -169,11 +202,10 @@ def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=No
     elif tuple(out.shape) != (n, c_out, t_out, v) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != y.device:
         raise RuntimeError(f"out must be a contiguous float32 {(n, c_out, t_out, v)} tensor on {y.device}")
     c_res, t_res = (x_res.shape[1], x_res.shape[2]) if x_res is not None else (0, 0)
-    rc = native.lib().csk_tcn_stage_f32(
-        native.ptr(y), native.ptr(w), native.ptr(x_res), native.ptr(w_res), native.ptr(bias), native.ptr(out),
-        n, c, c_out, t_in, v, k, stride, pad, res_mode, c_res, t_res, res_off, int(relu), native.stream_of(y),
-    )
-    native.check(rc, "csk_tcn_stage_f32")
+    fn = native.lib().csk_tcn_stage_bf16x3 if split else native.lib().csk_tcn_stage_f32
+    rc = fn(native.ptr(y), native.ptr(w), native.ptr(x_res), native.ptr(w_res), native.ptr(bias), native.ptr(out),
+            n, c, c_out, t_in, v, k, stride, pad, res_mode, c_res, t_res, res_off, int(relu), native.stream_of(y))
+    native.check(rc, "csk_tcn_stage_bf16x3" if split else "csk_tcn_stage_f32")
     return out
 
 
@@ -207,9 +239,12 @@ class SpatioTemporalBlock(_Folded):
             self.residual in (zero, unity) or isinstance(self.residual, TemporalConvolution)
         )
 
+    precision = "f32"      # or "bf16x3" (opt-in, set_precision): arithmetic of the temporal conv / residual conv kernels
+
     def _fold(self):
         sd = self.state_dict()
-        return fold.fold_block_tail(sd, "", has_conv_residual=isinstance(self.residual, TemporalConvolution))
+        return fold.fold_block_tail(sd, "", has_conv_residual=isinstance(self.residual, TemporalConvolution),
+                                    split=self.precision == "bf16x3")
 
     def forward(self, x, out=None):
         """``out`` (optional, native tail only): preallocated (N, C_out, T_out, V) tensor to write into."""
@@ -229,6 +264,9 @@ class SpatioTemporalBlock(_Folded):
             mode, xr = 1, x
         else:
             mode, xr = 2, x
+        if self.precision == "bf16x3":
+            return tcn_stage(y, ops["w_split"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
+                             res_mode=mode, x_res=xr, w_res=ops["w_res_split"], res_off=shrink, out=out, split=True)
         return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
                          res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out)
 

@@ -222,7 +222,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
                     k = plain + k[len(co):]
                     break
             sd[k] = v
-        return fold.fold_block_tail(sd, "", has_conv_residual=self.kind == "conv")
+        return fold.fold_block_tail(sd, "", has_conv_residual=self.kind == "conv", split=self.precision == "bf16x3")
 
     # ---- persistent state --------------------------------------------------------------------------
     def bind_state(self, p: int, device, xin: Optional[torch.Tensor] = None, max_emit: int = MAX_CYCLE,

@@ -34,6 +34,37 @@ def pack_conv_weight(weight: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     return out.float().contiguous()
 
 
+SPLIT_KS = 16     # channels per K step of the bf16x3 split kernels (csrc/tcn_split.hip)
+SPLIT_KP = 10     # CSK_SPLIT_KP: taps per channel chunk of a split 9-tap conv
+
+
+def split3_bf16(w32: torch.Tensor):
+    """fp32 -> three bf16 pieces h + m + l (round to nearest even each; the subtractions are exact in fp32)."""
+    h = w32.to(torch.bfloat16)
+    r1 = w32 - h.float()
+    m = r1.to(torch.bfloat16)
+    l = (r1 - m.float()).to(torch.bfloat16)
+    return h, m, l
+
+
+def pack_conv_weight_split(weight: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """(C_out, C_in, K, 1) conv weight * per-output scale -> the operand image of the bf16x3 split kernels
+    (include/cskel.h, csk_tcn_stage_bf16x3): int16 tensor [C_in_pad/16][Kp][3 pieces][2 halves][C_out_pad][8] holding
+    bf16 bit patterns; element [c16][r][pc][h][co][j] = piece pc of W'[co, 16*c16 + 8*h + j, r].  The pieces are taken
+    from the SAME fp32 value the exact-fp32 path packs (fp64 fold, one rounding to fp32), K = 9 -> Kp = 10 (zero tap), K = 1 -> 1."""
+    co, ci, k, _ = weight.shape
+    if k not in (1, 9):
+        raise ValueError(f"split weights are built for the 9 x 1 temporal conv and the 1 x 1 residual conv, got k = {k}")
+    kp = SPLIT_KP if k == 9 else 1
+    w32 = (weight.double()[:, :, :, 0] * scale[:, None, None]).float()            # (co, ci, k), as pack_conv_weight
+    cpad, mpad = _ceil_to(ci, SPLIT_KS), _ceil_to(co, MT)
+    full = torch.zeros((mpad, cpad, kp), dtype=torch.float32)
+    full[:co, :ci, :k] = w32
+    pieces = torch.stack([p.view(torch.int16) for p in split3_bf16(full)], 0)        # (3, mpad, cpad, kp)
+    out = pieces.view(3, mpad, cpad // SPLIT_KS, 2, 8, kp).permute(2, 5, 0, 3, 1, 4)  # [c16][kp][pc][h][co][j]
+    return out.contiguous()
+
+
 def pad_vec(v: torch.Tensor) -> torch.Tensor:
     out = torch.zeros(_ceil_to(v.numel(), MT), dtype=torch.float64)
     out[: v.numel()] = v
@@ -93,10 +124,19 @@ def fold_temporal_conv(sd: Dict[str, torch.Tensor], p: str = "") -> dict:
     return dict(w=pack_conv_weight(wt, s), bias=bias, c_in=wt.shape[1], c_out=wt.shape[0], k=wt.shape[2])
 
 
-def fold_block_tail(sd: Dict[str, torch.Tensor], p: str = "", has_conv_residual: Optional[bool] = None) -> dict:
-    """Operands of csk_tcn_stage_f32 for a whole SpatioTemporalBlock tail: tcn (+ conv residual)."""
+def fold_temporal_conv_split(sd: Dict[str, torch.Tensor], p: str = "") -> torch.Tensor:
+    """bf16x3 split image of a TemporalConvolution's weight (same BN fold as fold_temporal_conv)."""
+    s, _ = bn_affine(sd[p + "bn.weight"].cpu(), sd[p + "bn.bias"].cpu(), sd[p + "bn.running_mean"].cpu(),
+                     sd[p + "bn.running_var"].cpu())
+    return pack_conv_weight_split(sd[p + "t_conv.weight"].detach().cpu(), s)
+
+
+def fold_block_tail(sd: Dict[str, torch.Tensor], p: str = "", has_conv_residual: Optional[bool] = None,
+                    split: bool = False) -> dict:
+    """Operands of csk_tcn_stage_f32 for a whole SpatioTemporalBlock tail: tcn (+ conv residual).  split: also the
+    bf16x3 operand images ``w_split`` / ``w_res_split`` (precision mode "bf16x3", 9-tap convs only)."""
     main = fold_temporal_conv(sd, p + "tcn.")
-    out = dict(w=main["w"], k=main["k"], c=main["c_in"], c_out=main["c_out"], w_res=None, c_res=0)
+    out = dict(w=main["w"], k=main["k"], c=main["c_in"], c_out=main["c_out"], w_res=None, c_res=0, w_split=None, w_res_split=None)
     bias = main["bias"]
     if has_conv_residual is None:
         has_conv_residual = (p + "residual.t_conv.weight") in sd
@@ -104,6 +144,10 @@ def fold_block_tail(sd: Dict[str, torch.Tensor], p: str = "", has_conv_residual:
         res = fold_temporal_conv(sd, p + "residual.")
         out["w_res"], out["c_res"] = res["w"], res["c_in"]
         bias = bias + res["bias"]
+    if split:
+        out["w_split"] = fold_temporal_conv_split(sd, p + "tcn.")
+        if has_conv_residual:
+            out["w_res_split"] = fold_temporal_conv_split(sd, p + "residual.")
     out["bias"] = pad_vec(bias)
     return out
 

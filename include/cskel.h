@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 8
+#define CSK_ABI_VERSION 9
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
+#define CSK_SPLIT_KP 10 /* taps per channel chunk of the bf16x3 split weights of a 9-tap conv (padded to even) */
 
 /* residual forms of SpatioTemporalBlock (models/base.py:367-374) and GraphConvolution (:246-254) */
 #define CSK_RES_NONE 0
@@ -101,6 +102,23 @@ int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const 
                       const float *bias, float *out,
                       int n_seg, int c, int c_out, int t_in, int V, int k, int stride, int pad,
                       int res_mode, int c_res, int t_res, int res_off, int relu, void *stream);
+
+/*
+ * OPT-IN precision mode "bf16x3" of csk_tcn_stage_f32 (same reference method, models/base.py:302-304 + 376-387; same
+ * arguments and layouts except the weights): the 9 x 1 temporal conv and the 1 x 1 residual conv run on the bf16 matrix
+ * pipe with every fp32 operand split into three bf16 pieces (h + m + l, 24 significand bits) and the six piece products
+ * of order <= 2 accumulated in fp32 -- fp32-GRADE results (measured max error vs the oracle: profiles/r03_parity_report.json),
+ * not the exact fp32 arithmetic of csk_tcn_stage_f32.  Never selected implicitly: blocks.set_precision(module, "bf16x3").
+ *  w_split      packed split weights of the (k = 9) conv, BN scale folded: 16-byte vectors of 8 bf16 (8 consecutive
+ *               input channels), indexed [c_pad / 16][CSK_SPLIT_KP taps][3 pieces][2 channel halves][c_out_pad]
+ *               (taps >= 9 zero); fold.pack_conv_weight_split
+ *  w_res_split  the same for the 1 x 1 residual conv, one tap: [c_res_pad / 16][1][3][2][c_out_pad], or NULL
+ *  k            must be 9
+ */
+int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const float *x_res, const void *w_res_split,
+                         const float *bias, float *out,
+                         int n_seg, int c, int c_out, int t_in, int V, int k, int stride, int pad,
+                         int res_mode, int c_res, int t_res, int res_off, int relu, void *stream);
 
 /*
  * Input permute + data_bn + reshape, models/st_gcn/st_gcn.py:49-57 (clip) and

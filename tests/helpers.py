@@ -53,7 +53,7 @@ def max_err(a, b):
 # {test, max_abs_err, absmax_ref, tol, ...} -- appended to gpurun_out/parity_report.jsonl (or $CSK_PARITY_REPORT), so
 # the achieved margin is on record (a builder run is committed as profiles/r03_parity_report.json).
 TOL = 1e-4
-REF_CAP = 16.0
+REF_CAP = 32.0
 
 
 def _report_path():
