@@ -244,7 +244,7 @@ class SpatioTemporalBlock(_Folded):
     def _fold(self):
         sd = self.state_dict()
         return fold.fold_block_tail(sd, "", has_conv_residual=isinstance(self.residual, TemporalConvolution),
-                                    split=self.precision == "bf16x3")
+                                    split=self.precision == "bf16x3", stride=self.stride)
 
     def forward(self, x, out=None):
         """``out`` (optional, native tail only): preallocated (N, C_out, T_out, V) tensor to write into."""

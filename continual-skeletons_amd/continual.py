@@ -222,7 +222,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
                     k = plain + k[len(co):]
                     break
             sd[k] = v
-        return fold.fold_block_tail(sd, "", has_conv_residual=self.kind == "conv", split=self.precision == "bf16x3")
+        return fold.fold_block_tail(sd, "", has_conv_residual=self.kind == "conv", split=self.precision == "bf16x3", stride=self.stride)
 
     # ---- persistent state --------------------------------------------------------------------------
     def bind_state(self, p: int, device, xin: Optional[torch.Tensor] = None, max_emit: int = MAX_CYCLE,
@@ -269,6 +269,11 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         ``(first_out_slot, n_emit)`` for the emissions of these frames, or None.  ``flush`` pushes zero
         post-GCN frames instead (end padding)."""
         st, k = self._state, self.kernel_size
+        if self.precision != "f32":
+            raise NotImplementedError(
+                "precision 'bf16x3' covers the clip kernels only: in step mode every ring slot feeds ONE tap per emission, so "
+                "the split kernel would stage twice the bytes per MFMA of the clip form and is bound by staging, not by the "
+                "matrix pipe (priced in DESIGN.md); step with the default precision")
         if not 1 <= r <= MAX_CYCLE:
             raise ValueError(f"engine_advance handles 1..{MAX_CYCLE} frames per call, got {r}")
         s0, p = st.s, st.p

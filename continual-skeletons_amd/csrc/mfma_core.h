@@ -27,6 +27,7 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 int csk_ensure_lds(const void *kernel, size_t bytes);
 // diagnostic switches (runtime.hip): active only when CSK_DIAG was set when the library was loaded
 bool csk_diag_flag(const char *name);
+int csk_diag_int(const char *name);
 unsigned long long *csk_diag_stamps();
 static inline unsigned vmagic_of(int V) { return (unsigned)(((1ull << 32) + V - 1) / V); }
 

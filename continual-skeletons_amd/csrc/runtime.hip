@@ -43,6 +43,10 @@ extern "C" const char *csk_last_error(void) { return g_err; }
 // CSK_NOPRIO=1 drops the raised wave priority inside MFMA segments (tools/ab_probe.py).
 static const bool g_diag = getenv("CSK_DIAG") != nullptr;
 bool csk_diag_flag(const char *name) { return g_diag && getenv(name) != nullptr; }
+int csk_diag_int(const char *name) {
+    const char *v = g_diag ? getenv(name) : nullptr;
+    return v ? atoi(v) : 0;
+}
 unsigned long long *csk_diag_stamps() {
     if (!g_diag) return nullptr;
     const char *d = getenv("CSK_STAMPS");

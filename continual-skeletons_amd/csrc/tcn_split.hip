@@ -17,7 +17,7 @@
 //                                                       (coalesced along positions), splits them and writes 3 x 16 B
 // One activation tile (16 channels x span positions) serves all 9 taps (a tap is an address shift of V positions);
 // the weights of a 16-channel chunk (9 x 16 x MT x 6 B = 110 KB at MT = 128) do not fit next to it, so they are
-// staged in TG taps at a time (TG = 3: 36.9 KB; Bl 36.9 KB -> two workgroups per CU).
+// staged 3 taps at a time (36.9 KB per stage, two buffers).
 #include "mfma_core.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -25,14 +25,30 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int KS = 16;          // channels per K step / chunk of the split kernels
 
+// One "kind" of K-loop work: a conv over `ntaps` taps that are `fs` source frames apart, on 16-channel chunks of one
+// source tensor.  A stride-s temporal conv is s kinds (taps r = rho, rho + s, ... read only the source frames of one
+// residue class: DE-INTERLEAVED in the LDS tile they form a stride-1 conv, so a tile never holds frames a tap set does not
+// use and a tap is a shift of V positions for every stride); the 1 x 1 strided residual conv is one more kind (one tap).
+//   tile frame j  <->  source frame  stride * ta + foff + fs * j,   j < (tb - ta) + ntaps      (ta..tb: output frames of the tile)
+//   weights: [chunk][nst * 3 tap slots][3 pieces][2 halves][Mpad] 16-byte vectors, zero slots behind the last tap
+static constexpr int MAXKINDS = 5;
+struct SplitKind {
+    const float *src;
+    const u32x4 *w;
+    int64_t seg_stride, chan_stride;
+    int C, nchunks, T, fs, foff, ntaps, nst;
+};
+
 struct TcnSplitParams {
-    const float *y, *xres, *bias;
-    const u32x4 *w, *wres;        // packed split weights: [chunk][Kp][3][2][Mpad] vectors of 8 bf16 (fold.pack_conv_weight_split)
+    SplitKind kind[MAXKINDS];
+    int nkinds;
+    const float *xres, *bias;     // identity residual source, folded bias
     float *out;
-    int C, Cpad, Cout, Mpad, Tin, Tout, V, K, Kp, stride, pad;
-    int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
+    int Cout, Mpad, Tout, V, stride;
+    int res_mode, Cres, Tres, res_off, relu, ldb;
     unsigned vmagic, mtiles, qtiles;
     int nt, fast_epi;
+    int diag;   // CSK_DIAG + CSK_SPLIT_SKIP=<bits>: 1 weight staging, 2 activation staging, 4 MFMAs, 8 barriers skipped in the K loop (timing experiments)
 };
 
 // x -> (h, m, l) for 8 values: v_cvt_pk_bf16_f32 (round to nearest even) for the pieces, exact fp32 subtractions
@@ -47,68 +63,74 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m
     }
 }
 
-// weights of one stage (TG taps x 3 pieces x 2 k-halves x MT rows, 16 B each): a contiguous run of rows per
-// (tap, piece, half) in global memory, copied as it stands (register prefetch + ds_write_b128)
-template <int MT, int TG>
+// ---- stage kernel: 512 threads = 8 waves (two per SIMD), ONE workgroup per CU, tile MT x NT with MT * NT = 32768 (128 x 256
+// or 64 x 512; every wave a 64 x 64 block as in tcn.hip).  Compared with a 4-wave 128 x 128 tile at two workgroups per CU
+// (the first form, measured 0.75-1.24x the exact-fp32 kernel: two barriers and a full weight stage per 72 MFMAs) a staged
+// weight vector feeds twice the MFMAs, and the weight stages ping-pong between two LDS buffers so that a stage costs ONE
+// barrier: the next stage's weights are committed in front of this stage's MFMAs, the stage after that is in flight in
+// registers.  The activation tile is single-buffered (two buffers do not fit): one extra barrier pair per 16-channel chunk.
+static constexpr int NTH2 = 512;
+static constexpr int TG = 3, NSTAGE = 3;     // 9 taps = 3 weight stages of 3 taps
+
+template <int MT>
 struct WSplitStage {
-    static constexpr int NV = TG * 6 * MT;
-    static constexpr int WB = (NV + NTHREADS - 1) / NTHREADS;
-    unsigned goff[WB], loff[WB];
+    static constexpr int NV = TG * 6 * MT;                  // 16-byte vectors of a stage (3 tap slots)
+    static constexpr int WB = (NV + NTH2 - 1) / NTH2;
     u32x4 v[WB];
-    __device__ __forceinline__ void setup(int Mpad, int tid) {
+    // vector e = u * 512 + tid of the stage (surplus threads re-stage the last one); offsets are recomputed per use
+    // (MT is a power of two: a shift and a mask) instead of being held in registers
+    __device__ __forceinline__ void issue(const u32x4 *__restrict__ base, int Mpad, int tid) {
 #pragma unroll
         for (int u = 0; u < WB; ++u) {
-            const int e = min(u * NTHREADS + tid, NV - 1);
-            goff[u] = (unsigned)((e / MT) * Mpad + (e % MT));
-            loff[u] = (unsigned)e;
+            const int e = min(u * NTH2 + tid, NV - 1);
+            v[u] = base[(e / MT) * Mpad + (e % MT)];
         }
     }
-    __device__ __forceinline__ void issue(const u32x4 *__restrict__ base) {
+    __device__ __forceinline__ void commit(u32x4 *__restrict__ Wl, int tid) const {
 #pragma unroll
-        for (int u = 0; u < WB; ++u) v[u] = base[goff[u]];
-    }
-    __device__ __forceinline__ void commit(u32x4 *__restrict__ Wl) const {
-#pragma unroll
-        for (int u = 0; u < WB; ++u) Wl[loff[u]] = v[u];
+        for (int u = 0; u < WB; ++u) Wl[min(u * NTH2 + tid, NV - 1)] = v[u];
     }
 };
 
-// activations of one 16-channel chunk: wave w stages k-half h = w & 1 of the position sweeps (w >> 1), (w >> 1) + 2, ...
-// (64 positions each): per sweep a lane loads the 8 channels of its position, unconditionally (clamped address + select,
-// see BStage in mfma_core.h), and at commit time splits them into the three piece fragments.
-template <int NS2>
+// activations of one 16-channel chunk: wave w stages k-half h = w & 1 of the position sweeps (w >> 1) + 4 i (64 tile
+// positions each): per sweep a lane loads the 8 channels of its position, unconditionally (clamped address + select, see
+// BStage in mfma_core.h), and at commit time splits them into the three piece fragments.  setup() maps tile positions
+// to source positions for a kind (frame de-interleave, zero padding outside [0, T)).
+template <int NS4>
 struct BSplitStage {
-    unsigned goff[NS2], loff[NS2], valid;
+    unsigned goff[NS4], loff[NS4], valid;
     int h;
-    float v[NS2][8];
-    __device__ __forceinline__ void setup(int pbase, int span, int TV, int lane, int wave) {
+    float v[NS4][8];
+    __device__ __forceinline__ void setup(int f0, int fs, int nframes, int T, int V, unsigned vmagic, int lane, int wave) {
         h = wave & 1;
         valid = 0;
 #pragma unroll
-        for (int i = 0; i < NS2; ++i) {
-            const int j = min(((wave >> 1) + 2 * i) * 64 + lane, span - 1);
-            const int pp = pbase + j;
-            goff[i] = (unsigned)min(max(pp, 0), TV - 1);
+        for (int i = 0; i < NS4; ++i) {
+            const int j = min(((wave >> 1) + 4 * i) * 64 + lane, nframes * V - 1);      // tile position
+            const int jf = div_magic(j, vmagic), f = f0 + fs * jf;
+            goff[i] = (unsigned)(min(max(f, 0), T - 1) * V + (j - jf * V));
             loff[i] = (unsigned)j;
-            valid |= (pp >= 0 && pp < TV) ? (1u << i) : 0u;
-        }
-    }
-    __device__ __forceinline__ void issue_sweep(int i, const float *__restrict__ seg_base, int C, int64_t cs, int c0) {
-        if (i >= NS2) return;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = c0 + 8 * h + j;
-            const float x = seg_base[(int64_t)min(c, C - 1) * cs + goff[i]];
-            v[i][j] = (c < C && ((valid >> i) & 1u)) ? x : 0.f;
+            valid |= (f >= 0 && f < T) ? (1u << i) : 0u;
         }
     }
     __device__ __forceinline__ void issue(const float *__restrict__ seg_base, int C, int64_t cs, int c0) {
+        // (the mask is formed per channel row and applied with a plain select: a short-circuit `c < C && bit` makes hipcc
+        // branch around every load and wait for each one separately)
 #pragma unroll
-        for (int i = 0; i < NS2; ++i) issue_sweep(i, seg_base, C, cs, c0);
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + 8 * h + j;
+            const float *src = seg_base + (int64_t)min(c, C - 1) * cs;
+            const unsigned m = c < C ? valid : 0u;
+#pragma unroll
+            for (int i = 0; i < NS4; ++i) {
+                const float x = src[goff[i]];
+                v[i][j] = ((m >> i) & 1u) ? x : 0.f;
+            }
+        }
     }
     __device__ __forceinline__ void commit(u32x4 *__restrict__ Bl, int ldb) const {
 #pragma unroll
-        for (int i = 0; i < NS2; ++i) {
+        for (int i = 0; i < NS4; ++i) {
             bf16x8 ph, pm, pl;
             split8(v[i], ph, pm, pl);
             u32x4 *dst = Bl + h * ldb + loff[i];
@@ -119,12 +141,14 @@ struct BSplitStage {
     }
 };
 
-// nt taps of the staged weights against the activation tile: per tap 12 ds_read_b128 (3 pieces x (2 row + 2 column
-// blocks)) and 24 MFMAs (6 piece products x 2 x 2 blocks), small products first
-template <int MT>
-__device__ __forceinline__ void mfma_split_taps(const u32x4 *__restrict__ Wl, const u32x4 *__restrict__ Bl, int nt, int ldb,
-                                                int tapB, int offA, int off0, int off1, int kh, f32x16 (&acc)[2][2]) {
-    for (int t = 0; t < nt; ++t) {
+// NTAP taps of the staged weights against the activation tile: per tap 12 ds_read_b128 (3 pieces x (2 row + 2 column
+// blocks)) and 24 MFMAs (6 piece products x 2 x 2 blocks), small products first.  Unrolled over the taps of a stage so
+// that the scheduler can run a tap's fragment reads under the previous tap's MFMAs.
+template <int MT, int NTAP>
+__device__ __forceinline__ void mfma_split_taps(const u32x4 *__restrict__ Wl, const u32x4 *__restrict__ Bl, int ldb, int tapB,
+                                                int offA, int off0, int off1, int kh, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
         const u32x4 *wr = Wl + (t * 6 + kh) * MT + offA;
         const u32x4 *br = Bl + kh * ldb + t * tapB;
         bf16x8 a[3][2], b[3][2];
@@ -146,14 +170,30 @@ __device__ __forceinline__ void mfma_split_taps(const u32x4 *__restrict__ Wl, co
     }
 }
 
-template <int MT, int NS2, int TG>
-__global__ __launch_bounds__(NTHREADS, 2) void tcn_split_stage_kernel(const TcnSplitParams p) {
-    constexpr int NT = 16384 / MT;
+// cursor over the K loop's (kind, chunk, stage) triples -- all wave-uniform scalars
+struct SplitCursor {
+    int k, c, s;
+    __device__ __forceinline__ bool valid(const TcnSplitParams &p) const { return k < p.nkinds; }
+    __device__ __forceinline__ void next_stage(const TcnSplitParams &p) {
+        if (++s == p.kind[k].nst) { s = 0; next_tile(p); }
+    }
+    __device__ __forceinline__ void next_tile(const TcnSplitParams &p) {
+        s = 0;
+        if (++c == p.kind[k].nchunks) { c = 0; ++k; }
+    }
+    __device__ __forceinline__ const u32x4 *wptr(const TcnSplitParams &p, int m0) const {
+        const SplitKind &kd = p.kind[k];
+        return kd.w + ((int64_t)(c * kd.nst + s) * TG * 6) * p.Mpad + m0;
+    }
+};
+
+template <int MT, int NS4>
+__global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplitParams p) {
     constexpr int WM = MT / 64;
-    constexpr int S = (9 + TG - 1) / TG;                    // weight stages of the 9-tap phase
+    constexpr int WSZ = TG * 6 * MT;                        // vectors of one weight buffer
     extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
-    u32x4 *Wl = smem4;                                      // [TG][3][2][MT]
-    u32x4 *Bl = smem4 + TG * 6 * MT;                        // [3][2][ldb]
+    u32x4 *Wl0 = smem4;                                     // 2 x [TG][3][2][MT]
+    u32x4 *Bl = smem4 + 2 * WSZ;                            // [3][2][ldb]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
@@ -165,12 +205,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_split_stage_kernel(const TcnS
     const int qend = min(q0 + p.nt, Q);
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
 
-    int off[2];
+    int off[2];                                             // this lane's two columns inside the (de-interleaved) tile
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int q = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
-        const int t = div_magic(q, p.vmagic);
-        off[ni] = p.stride * (t - ta) * V + (q - t * V);
+        off[ni] = q - ta * V;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -181,65 +220,69 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_split_stage_kernel(const TcnS
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
     const int offA = wm * 64 + l31;
 
-    WSplitStage<MT, TG> ws;
-    BSplitStage<NS2> bs;
-    ws.setup(p.Mpad, tid);
-    // ---- phase 1: 9 x 1 temporal conv over y, chunks of 16 channels, S weight stages per chunk
+    WSplitStage<MT> ws;
+    BSplitStage<NS4> bs;
+    // ---- K loop: a flat sequence of weight stages g (3 tap slots each); Wl[g & 1] holds stage g, the registers hold stage
+    // g + 1 until it is committed in front of stage g's MFMAs, stage g + 2 is then issued.  The activation tile of the
+    // current (kind, chunk) sits in Bl, the next tile's values are in flight in registers.
     {
-        const int fa = p.stride * ta - p.pad;
-        const int span = (p.stride * (tb - ta) + p.K) * V;
-        const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V;
-        const int64_t cs = (int64_t)p.Tin * V;
-        const u32x4 *wbase = p.w + m0;
-        const int64_t stage_stride = (int64_t)TG * 6 * p.Mpad, chunk_stride = (int64_t)p.Kp * 6 * p.Mpad;
-        bs.setup(fa * V, span, p.Tin * V, lane, wave);
-        ws.issue(wbase);
-        bs.issue(seg_base, p.C, cs, 0);
-        const int nchunks = p.Cpad / KS;
-        for (int c = 0; c < nchunks; ++c) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                __syncthreads();                       // the previous stage's LDS reads are done
-                ws.commit(Wl);
-                if (s == 0) bs.commit(Bl, p.ldb);
-                __syncthreads();
-                // next stage's weights; the next chunk's activations go out one sweep per stage
-                const bool last = s == S - 1;
-                const int cn = last ? c + 1 : c, sn = last ? 0 : s + 1;
-                if (cn < nchunks) ws.issue(wbase + cn * chunk_stride + sn * stage_stride);
-                if (c + 1 < nchunks) {
-#pragma unroll
-                    for (int i = s; i < NS2; i += S) bs.issue_sweep(i, seg_base, p.C, cs, (c + 1) * KS);
-                }
-                const int ntap = min(TG, p.K - s * TG);
-                __builtin_amdgcn_s_setprio(1);
-                mfma_split_taps<MT>(Wl, Bl + s * TG * V, ntap, p.ldb, V, offA, off[0], off[1], kh, acc);
-                __builtin_amdgcn_s_setprio(0);
-            }
+        auto setup_b = [&](int k) {
+            const SplitKind &kd = p.kind[k];
+            bs.setup(p.stride * ta + kd.foff, kd.fs, (tb - ta) + kd.ntaps, kd.T, V, p.vmagic, lane, wave);
+        };
+        auto issue_b = [&](const SplitCursor &t) {
+            const SplitKind &kd = p.kind[t.k];
+            bs.issue(kd.src + (int64_t)seg * kd.seg_stride, kd.C, kd.chan_stride, t.c * KS);
+        };
+        SplitCursor G{0, 0, 0}, G1{0, 0, 0}, G2{0, 0, 0}, T1{0, 0, 0};
+        G1.next_stage(p);
+        G2.next_stage(p); G2.next_stage(p);
+        T1.next_tile(p);
+        ws.issue(G.wptr(p, m0), p.Mpad, tid);
+        setup_b(0);
+        issue_b(G);
+        ws.commit(Wl0, tid);
+        bs.commit(Bl, p.ldb);
+        if (G1.valid(p)) ws.issue(G1.wptr(p, m0), p.Mpad, tid);
+        int bkind = 0;
+        if (T1.valid(p)) {
+            if (T1.k != bkind) { bkind = T1.k; setup_b(bkind); }
+            issue_b(T1);
         }
-    }
-    // ---- phase 2: 1 x 1 strided residual conv over the block input (models/base.py:372-374): one tap, one stage per chunk
-    if (p.res_mode == CSK_RES_CONV) {
-        const int fa = p.stride * ta + p.res_off;
-        const int span = (p.stride * (tb - ta) + 1) * V;
-        const float *seg_base = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
-        const int64_t cs = (int64_t)p.Tres * V;
-        const u32x4 *wbase = p.wres + m0;
-        const int64_t chunk_stride = (int64_t)6 * p.Mpad;      // Kp = 1
-        bs.setup(fa * V, span, p.Tres * V, lane, wave);
-        ws.issue(wbase);
-        bs.issue(seg_base, p.Cres, cs, 0);
-        const int nchunks = p.CresPad / KS;
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();
-            ws.commit(Wl);                              // (surplus vectors of the stage are clamped duplicates / pad taps: never read)
-            bs.commit(Bl, p.ldb);
-            __syncthreads();
-            if (c + 1 < nchunks) {
-                ws.issue(wbase + (c + 1) * chunk_stride);
-                bs.issue(seg_base, p.Cres, cs, (c + 1) * KS);
+        __syncthreads();
+        int g = 0;
+        while (G.valid(p)) {
+            const SplitKind &kd = p.kind[G.k];
+            const int nst = kd.nst;
+            for (int s = 0; s < nst; ++s) {
+                u32x4 *cur = Wl0 + (g & 1) * WSZ, *oth = Wl0 + ((g & 1) ^ 1) * WSZ;
+                if (G1.valid(p) && !(p.diag & 1)) ws.commit(oth, tid);     // stage g + 1 (loaded during stage g - 1)
+                if (G2.valid(p) && !(p.diag & 1)) ws.issue(G2.wptr(p, m0), p.Mpad, tid);
+                const int ntap = min(TG, kd.ntaps - s * TG);
+                const u32x4 *bl = Bl + s * TG * V;
+                __builtin_amdgcn_s_setprio(1);
+                if (!(p.diag & 4)) {
+                    if (ntap == 3) mfma_split_taps<MT, 3>(cur, bl, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    else
+                        for (int t = 0; t < ntap; ++t)
+                            mfma_split_taps<MT, 1>(cur + t * 6 * MT, bl + t * V, p.ldb, V, offA, off[0], off[1], kh, acc);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (!(p.diag & 8)) __syncthreads();                        // stage g's reads done, stage g + 1's weights visible
+                G.next_stage(p); G1.next_stage(p); G2.next_stage(p);
+                ++g;
             }
-            mfma_split_taps<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
+            if (T1.valid(p) && !(p.diag & 2)) {                            // tile boundary: the next activation tile
+                bs.commit(Bl, p.ldb);
+                T1.next_tile(p);
+                if (T1.valid(p)) {
+                    if (T1.k != bkind) { bkind = T1.k; setup_b(bkind); }
+                    issue_b(T1);
+                }
+                if (!(p.diag & 8)) __syncthreads();
+            } else if (p.diag & 2) {
+                T1.next_tile(p);
+            }
         }
     }
     // ---- epilogue: + bias (+ identity residual), ReLU, stores -- the scheme of tcn_stage_kernel (scalar row bases + 32-bit
@@ -325,7 +368,7 @@ extern "C" int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const f
     if (!y || !w_split || !bias || !out) CSK_FAIL("tcn_stage_bf16x3: null pointer");
     if (n_seg <= 0 || c <= 0 || c_out <= 0 || t_in <= 0 || V < 2 || V > 64) CSK_FAIL("tcn_stage_bf16x3: bad dims");
     if (k != 9) CSK_FAIL("tcn_stage_bf16x3: the split kernel is built for the 9 x 1 temporal conv (k = %d); use csk_tcn_stage_f32", k);
-    if (stride < 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage_bf16x3: bad stride/pad");
+    if (stride < 1 || stride > MAXKINDS - 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage_bf16x3: bad stride/pad (stride <= %d)", MAXKINDS - 1);
     if (t_in + 2 * pad < k) CSK_FAIL("tcn_stage_bf16x3: t_in too short for kernel");
     const int t_out = (t_in + 2 * pad - k) / stride + 1;
     if (res_mode != CSK_RES_NONE) {
@@ -337,41 +380,54 @@ extern "C" int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const f
     if ((int64_t)t_in * V >= (1 << 26)) CSK_FAIL("tcn_stage_bf16x3: T*V too large for 32-bit position arithmetic");
     if (((uintptr_t)w_split | (uintptr_t)(w_res_split ? w_res_split : w_split)) & 15) CSK_FAIL("tcn_stage_bf16x3: packed weights must be 16-byte aligned");
     TcnSplitParams p;
-    p.y = y; p.w = (const u32x4 *)w_split; p.xres = x_res ? x_res : y; p.wres = (const u32x4 *)w_res_split; p.bias = bias; p.out = out;
-    p.C = c; p.Cpad = round_up(c, KS); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
-    p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.Kp = CSK_SPLIT_KP; p.stride = stride; p.pad = pad;
-    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, KS);
-    p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
+    p.xres = x_res ? x_res : y; p.bias = bias; p.out = out;
+    p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT); p.Tout = t_out; p.V = V; p.stride = stride;
+    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu;
+    p.vmagic = vmagic_of(V);
     p.fast_epi = (int64_t)p.Tres * V < (1ll << 27) && (int64_t)t_out * V < (1ll << 27);
+    p.diag = csk_diag_int("CSK_SPLIT_SKIP");
+    // kinds: one per residue class of the taps modulo the stride (fold.pack_conv_weight_split lays the weights out in
+    // this order, back to back), then the residual conv
+    const int nch = round_up(c, KS) / KS;
+    p.nkinds = 0;
+    const u32x4 *wp = (const u32x4 *)w_split;
+    for (int rho = 0; rho < stride && rho < k; ++rho) {
+        SplitKind &kd = p.kind[p.nkinds++];
+        kd.src = y; kd.w = wp; kd.seg_stride = (int64_t)c * t_in * V; kd.chan_stride = (int64_t)t_in * V;
+        kd.C = c; kd.nchunks = nch; kd.T = t_in; kd.fs = stride; kd.foff = rho - pad;
+        kd.ntaps = (k - rho + stride - 1) / stride; kd.nst = (kd.ntaps + TG - 1) / TG;
+        wp += (int64_t)nch * kd.nst * TG * 6 * p.Mpad;
+    }
+    if (res_mode == CSK_RES_CONV) {
+        SplitKind &kd = p.kind[p.nkinds++];
+        kd.src = x_res; kd.w = (const u32x4 *)w_res_split; kd.seg_stride = (int64_t)c_res * t_res * V; kd.chan_stride = (int64_t)t_res * V;
+        kd.C = c_res; kd.nchunks = round_up(c_res, KS) / KS; kd.T = t_res; kd.fs = stride; kd.foff = res_off; kd.ntaps = 1; kd.nst = 1;
+    }
     const bool big = (p.Mpad % 128) == 0;
-    const int MT = big ? 128 : 64, NT = 16384 / MT;
-    // activation sweeps: at most 10 x 64 positions of a row are staged (5 per wave: the widest spill-free instantiation);
-    // longer input spans (stride 3 with many joints, ...) narrow the tile -- never the case for the ST-GCN shapes
+    const int MT = big ? 128 : 64, NT = 32768 / MT;
+    // a tile stages (frames spanned + 9) * V positions per 16-byte row, whatever the stride (frames are de-interleaved): at
+    // most 16 (64-row tiles) / 12 (128-row tiles) x 64 positions (4 / 3 sweeps per wave), and the tile must fit the CU's LDS next to the two weight buffers; more
+    // joints than that narrow the tile -- never the case for the skeleton shapes (V <= 25: 500 / 752 positions)
+    const size_t wl = (size_t)2 * TG * 6 * MT * 16;
     p.nt = NT;
     for (;;) {
         const int max_dt = (p.nt + V - 2) / V;
-        p.ldb = round_up((stride * max_dt + k) * V, 4);
-        if ((p.ldb + 63) / 64 <= 10 || p.nt == 1) break;
+        p.ldb = round_up((max_dt + k) * V, 4);
+        if (((p.ldb + 63) / 64 <= (big ? 12 : 16) && wl + (size_t)6 * p.ldb * 16 <= 160 * 1024) || p.nt == 1) break;
         p.nt = p.nt > 16 ? p.nt - 16 : 1;
     }
     const int nj = (p.ldb + 63) / 64;
-    if (nj > 10) CSK_FAIL("tcn_stage_bf16x3: activation tile of %d positions exceeds the staged maximum (640)", p.ldb);
-    const int ns2 = (nj + 1) / 2;
-    // weight stage depth: 3 taps if the tile then still fits two workgroups per CU (80 KB each), else 2 (also for the
-    // 128-row tiles with more than 3 sweeps per wave: their 3-tap form spills)
-    const size_t bl = (size_t)6 * p.ldb * 16;
-    const int TG = ((size_t)3 * 6 * MT * 16 + bl <= 80 * 1024 && !(big && ns2 > 3)) ? 3 : 2;
-    const size_t lds = (size_t)TG * 6 * MT * 16 + bl;
-    if (lds > 160 * 1024) CSK_FAIL("tcn_stage_bf16x3: LDS tile %zu B exceeds 160 KiB", lds);
+    const size_t lds = wl + (size_t)6 * p.ldb * 16;
+    if (nj > (big ? 12 : 16) || lds > 160 * 1024) CSK_FAIL("tcn_stage_bf16x3: activation tile of %d positions exceeds the staged maximum", p.ldb);
+    const int ns4 = (nj + 3) / 4;
     const int Q = t_out * V;
     p.qtiles = (Q + p.nt - 1) / p.nt; p.mtiles = p.Mpad / MT;
     if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage_bf16x3: grid too large");
     dim3 grid(p.qtiles * p.mtiles * n_seg);
     void (*kern)(TcnSplitParams);
-    if (big) kern = TG == 3 ? tcn_split_stage_kernel<128, 3, 3> : (ns2 <= 3 ? tcn_split_stage_kernel<128, 3, 2> : tcn_split_stage_kernel<128, 5, 2>);
-    else kern = TG == 3 ? (ns2 <= 3 ? tcn_split_stage_kernel<64, 3, 3> : tcn_split_stage_kernel<64, 5, 3>)
-                        : (ns2 <= 3 ? tcn_split_stage_kernel<64, 3, 2> : tcn_split_stage_kernel<64, 5, 2>);
+    if (big) kern = ns4 <= 2 ? tcn_split_stage_kernel<128, 2> : tcn_split_stage_kernel<128, 3>;      // (4 sweeps per wave would spill)
+    else kern = ns4 <= 2 ? tcn_split_stage_kernel<64, 2> : ns4 == 3 ? tcn_split_stage_kernel<64, 3> : tcn_split_stage_kernel<64, 4>;
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NTH2), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

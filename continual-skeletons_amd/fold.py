@@ -35,7 +35,6 @@ def pack_conv_weight(weight: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
 
 
 SPLIT_KS = 16     # channels per K step of the bf16x3 split kernels (csrc/tcn_split.hip)
-SPLIT_KP = 10     # CSK_SPLIT_KP: taps per channel chunk of a split 9-tap conv
 
 
 def split3_bf16(w32: torch.Tensor):
@@ -47,22 +46,31 @@ def split3_bf16(w32: torch.Tensor):
     return h, m, l
 
 
-def pack_conv_weight_split(weight: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+def pack_conv_weight_split(weight: torch.Tensor, scale: torch.Tensor, stride: int = 1) -> torch.Tensor:
     """(C_out, C_in, K, 1) conv weight * per-output scale -> the operand image of the bf16x3 split kernels
-    (include/cskel.h, csk_tcn_stage_bf16x3): int16 tensor [C_in_pad/16][Kp][3 pieces][2 halves][C_out_pad][8] holding
-    bf16 bit patterns; element [c16][r][pc][h][co][j] = piece pc of W'[co, 16*c16 + 8*h + j, r].  The pieces are taken
-    from the SAME fp32 value the exact-fp32 path packs (fp64 fold, one rounding to fp32), K = 9 -> Kp = 10 (zero tap), K = 1 -> 1."""
+    (include/cskel.h, csk_tcn_stage_bf16x3), an int16 tensor of bf16 bit patterns.
+
+    A stride-s conv is laid out as s "kinds", one per residue class rho of the taps (r = rho, rho + s, ...: the taps that
+    read the same de-interleaved set of source frames), back to back; a kind is
+        [C_in_pad / 16][nst * 3 tap slots][3 pieces][2 channel halves][C_out_pad][8 channels]
+    with nst = ceil(n_taps / 3) weight stages of 3 tap slots (zero slots behind the last tap); element
+    [c16][slot][pc][h][co][j] = piece pc of W'[co, 16 c16 + 8 h + j, rho + s * slot].  K = 1 (the residual conv) is one
+    kind with one tap.  The pieces are taken from the SAME fp32 value the exact-fp32 path packs (fp64 fold, one rounding)."""
     co, ci, k, _ = weight.shape
     if k not in (1, 9):
         raise ValueError(f"split weights are built for the 9 x 1 temporal conv and the 1 x 1 residual conv, got k = {k}")
-    kp = SPLIT_KP if k == 9 else 1
     w32 = (weight.double()[:, :, :, 0] * scale[:, None, None]).float()            # (co, ci, k), as pack_conv_weight
     cpad, mpad = _ceil_to(ci, SPLIT_KS), _ceil_to(co, MT)
-    full = torch.zeros((mpad, cpad, kp), dtype=torch.float32)
-    full[:co, :ci, :k] = w32
-    pieces = torch.stack([p.view(torch.int16) for p in split3_bf16(full)], 0)        # (3, mpad, cpad, kp)
-    out = pieces.view(3, mpad, cpad // SPLIT_KS, 2, 8, kp).permute(2, 5, 0, 3, 1, 4)  # [c16][kp][pc][h][co][j]
-    return out.contiguous()
+    kinds = []
+    for rho in range(min(stride if k > 1 else 1, k)):
+        taps = list(range(rho, k, stride if k > 1 else 1))
+        slots = _ceil_to(len(taps), 3)
+        full = torch.zeros((mpad, cpad, slots), dtype=torch.float32)
+        full[:co, :ci, : len(taps)] = w32[:, :, taps]
+        pieces = torch.stack([p.view(torch.int16) for p in split3_bf16(full)], 0)        # (3, mpad, cpad, slots)
+        out = pieces.view(3, mpad, cpad // SPLIT_KS, 2, 8, slots).permute(2, 5, 0, 3, 1, 4)  # [c16][slot][pc][h][co][j]
+        kinds.append(out.contiguous().reshape(-1))
+    return torch.cat(kinds).contiguous()
 
 
 def pad_vec(v: torch.Tensor) -> torch.Tensor:
@@ -124,15 +132,15 @@ def fold_temporal_conv(sd: Dict[str, torch.Tensor], p: str = "") -> dict:
     return dict(w=pack_conv_weight(wt, s), bias=bias, c_in=wt.shape[1], c_out=wt.shape[0], k=wt.shape[2])
 
 
-def fold_temporal_conv_split(sd: Dict[str, torch.Tensor], p: str = "") -> torch.Tensor:
+def fold_temporal_conv_split(sd: Dict[str, torch.Tensor], p: str = "", stride: int = 1) -> torch.Tensor:
     """bf16x3 split image of a TemporalConvolution's weight (same BN fold as fold_temporal_conv)."""
     s, _ = bn_affine(sd[p + "bn.weight"].cpu(), sd[p + "bn.bias"].cpu(), sd[p + "bn.running_mean"].cpu(),
                      sd[p + "bn.running_var"].cpu())
-    return pack_conv_weight_split(sd[p + "t_conv.weight"].detach().cpu(), s)
+    return pack_conv_weight_split(sd[p + "t_conv.weight"].detach().cpu(), s, stride)
 
 
 def fold_block_tail(sd: Dict[str, torch.Tensor], p: str = "", has_conv_residual: Optional[bool] = None,
-                    split: bool = False) -> dict:
+                    split: bool = False, stride: int = 1) -> dict:
     """Operands of csk_tcn_stage_f32 for a whole SpatioTemporalBlock tail: tcn (+ conv residual).  split: also the
     bf16x3 operand images ``w_split`` / ``w_res_split`` (precision mode "bf16x3", 9-tap convs only)."""
     main = fold_temporal_conv(sd, p + "tcn.")
@@ -145,7 +153,7 @@ def fold_block_tail(sd: Dict[str, torch.Tensor], p: str = "", has_conv_residual:
         out["w_res"], out["c_res"] = res["w"], res["c_in"]
         bias = bias + res["bias"]
     if split:
-        out["w_split"] = fold_temporal_conv_split(sd, p + "tcn.")
+        out["w_split"] = fold_temporal_conv_split(sd, p + "tcn.", stride)
         if has_conv_residual:
             out["w_res_split"] = fold_temporal_conv_split(sd, p + "residual.")
     out["bias"] = pad_vec(bias)

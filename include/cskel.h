@@ -31,7 +31,6 @@ extern "C" {
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
-#define CSK_SPLIT_KP 10 /* taps per channel chunk of the bf16x3 split weights of a 9-tap conv (padded to even) */
 
 /* residual forms of SpatioTemporalBlock (models/base.py:367-374) and GraphConvolution (:246-254) */
 #define CSK_RES_NONE 0
@@ -110,10 +109,12 @@ int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const 
  * of order <= 2 accumulated in fp32 -- fp32-GRADE results (measured max error vs the oracle: profiles/r03_parity_report.json),
  * not the exact fp32 arithmetic of csk_tcn_stage_f32.  Never selected implicitly: blocks.set_precision(module, "bf16x3").
  *  w_split      packed split weights of the (k = 9) conv, BN scale folded: 16-byte vectors of 8 bf16 (8 consecutive
- *               input channels), indexed [c_pad / 16][CSK_SPLIT_KP taps][3 pieces][2 channel halves][c_out_pad]
- *               (taps >= 9 zero); fold.pack_conv_weight_split
- *  w_res_split  the same for the 1 x 1 residual conv, one tap: [c_res_pad / 16][1][3][2][c_out_pad], or NULL
- *  k            must be 9
+ *               input channels).  One "kind" per residue class rho < stride of the taps (r = rho, rho + stride, ...: they
+ *               read one de-interleaved set of source frames), back to back; a kind is indexed
+ *               [c_pad / 16][nst * 3 tap slots][3 pieces][2 channel halves][c_out_pad], nst = ceil(n_taps / 3), zero
+ *               slots behind the last tap (fold.pack_conv_weight_split)
+ *  w_res_split  the same for the 1 x 1 residual conv: one kind, one tap, [c_res_pad / 16][3][3][2][c_out_pad], or NULL
+ *  k            must be 9; stride <= 4
  */
 int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const float *x_res, const void *w_res_split,
                          const float *bias, float *out,

@@ -133,6 +133,23 @@ def test_config2_batch256_clip_forward_bf16x3():
     assert torch.equal(part, full[64:128])
 
 
+def test_continual_stepping_refuses_bf16x3_but_clip_forward_works():
+    """The split kernels exist for the clip form only: a continual block in bf16x3 mode computes ``forward`` (clip) with
+    them and refuses to step (no silent fall-back to another arithmetic)."""
+    a, sd = load_golden("g3_block_ident")
+    ci, co, s, res, tp = (int(v) for v in a["meta"])
+    blk = pkg.CoSpatioTemporalBlock(ci, co, _A(), stride=s, residual=bool(res), padding="equal").eval()
+    blk.load_state_dict(sd, strict=True)
+    pkg.set_precision(blk, MODE)
+    blk = blk.to(DEV)
+    x = torch.from_numpy(a["x"]).to(DEV)
+    check_parity(blk.forward(x).cpu(), a["y"], mode=MODE)
+    with pytest.raises(NotImplementedError, match="clip kernels only"):
+        blk.forward_step(x[:, :, 0].contiguous())
+    pkg.set_precision(blk, "f32")
+    assert blk.forward_step(x[:, :, 0].contiguous()) is None       # back to the default: stepping works (no output yet)
+
+
 def test_precision_argument_errors():
     m = pkg.SpatioTemporalBlock(4, 4, _A()).eval()
     with pytest.raises(ValueError, match="precision must be"):

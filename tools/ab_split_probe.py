@@ -51,5 +51,20 @@ for ci, co, s, T in shapes:
             times[split].append(e0.elapsed_time(e1) / 3)
     flop = 2.0 * 2 * batch * t_out * 25 * (9 * co * co + (ci * co if mode == 2 else 0))
     m32, m3 = statistics.median(times[False]), statistics.median(times[True])
+    if os.environ.get("CSK_DIAG"):          # where does the split kernel's time go?  (results are garbage with skips on)
+        parts = []
+        for bits in (0, 1, 2, 3, 4, 8, 11, 7):
+            os.environ["CSK_SPLIT_SKIP"] = str(bits)
+            run(True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run(True)
+            e1.record()
+            torch.cuda.synchronize()
+            parts.append(f"skip{bits}={e0.elapsed_time(e1) / 3:.3f}")
+        os.environ["CSK_SPLIT_SKIP"] = "0"
+        print("   SPLIT_DIAG (1 = W staging, 2 = B staging, 4 = MFMA, 8 = barriers): " + " ".join(parts))
     print(f"SPLIT_AB {ci}->{co} s{s} T={T}: f32 {m32:.3f} ms ({flop / m32 / 1e9:.1f} TF)  bf16x3 {m3:.3f} ms ({flop / m3 / 1e9:.1f} TF-equiv)  "
           f"speedup {m32 / m3:.2f}x  max|diff| {err:.2e}  |out|max {float(ref.abs().max()):.2f}")

@@ -37,7 +37,7 @@ def klass(name):
         return "a"
     if "gcn_stage" in name:
         return "g"
-    if "tcn_step" in name or "tcn_stage" in name:
+    if "tcn_step" in name or "tcn_stage" in name or "tcn_split" in name:
         return "t"
     if "co_block" in name:
         return "f"
