@@ -353,6 +353,7 @@ def main():
                     help="clips per GPU of the configs[4] leg (8192 / 8 GPUs), run when more than one rank is launched")
     ap.add_argument("--config4-batch", type=int, default=64, help="A-GCN clips of the configs[3] clip leg")
     ap.add_argument("--config4-streams", type=int, default=1024, help="CoAGCN streams of the configs[3] online leg")
+    ap.add_argument("--no-split-leg", action="store_true", help="skip the opt-in bf16x3 precision-mode leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=50.0, help="seconds of CPU work the configs[1]/[2] cpu_baseline legs may take in all")
     ap.add_argument("--cpu-budget-config4", type=float, default=14.0, help="seconds of CPU work for the two configs[3] cpu_baseline legs")
@@ -420,12 +421,16 @@ def main():
     line = None
     B = args.batch
 
-    def clip_leg(batch, steps, warmup, seed0=100):
+    def clip_leg(batch, steps, warmup, seed0=100, precision="f32", info=None):
         """`steps` timed clip forwards of `batch` clips per rank (+ the logit all-gather when ranks > 1), bracketed by
-        barrier + synchronize; returns (max-over-ranks seconds, tcn_stage HIP-event ms, launches timed)."""
+        barrier + synchronize; returns (max-over-ranks seconds, tcn_stage HIP-event ms, launches timed).  precision
+        "bf16x3": the opt-in split arithmetic of the temporal conv (blocks.set_precision); info["max_abs_diff_vs_f32"] then
+        receives the largest logit difference against the default path on the same weights and input."""
         net = pkg.StGcn(pkg.ntu_graph().A, input_shape=(NTU["C"], NTU["T"], NTU["V"], NTU["M"]), num_classes=NTU["classes"]).eval()
         randomise_(net, seed=0)                              # identical weights on every rank
         net = net.to(dev)
+        if precision != "f32":
+            pkg.set_precision(net, precision)
         x = torch.rand((batch, NTU["C"], NTU["T"], NTU["V"], NTU["M"]), device=dev,
                        generator=torch.Generator(device=dev).manual_seed(seed0 + rank))
 
@@ -452,6 +457,13 @@ def main():
             n_launch = len(lt.records)
         assert out.shape == (batch * world, NTU["classes"]) and bool(torch.isfinite(out).all())
         dt = max_over_ranks(dt)
+        if info is not None and precision != "f32":
+            got = net(x)
+            pkg.set_precision(net, "f32")
+            ref = net(x)
+            info["max_abs_diff_vs_f32"] = float((got - ref).abs().max())
+            info["logit_absmax"] = float(ref.abs().max())
+            del got, ref
         del x, out, net
         gc.collect()                 # engines hold reference cycles (state-dict hooks); free their slabs now
         torch.cuda.empty_cache()
@@ -490,6 +502,26 @@ def main():
             "cpu_baseline": cpu,
             "ranks_seen": ranks_seen(), "collective_backend": backend if use_dist else None,
         }
+        if not args.no_split_leg:
+            # OPT-IN precision mode "bf16x3" (csrc/tcn_split.hip): the same workload with the temporal conv on the bf16 matrix
+            # pipe (fp32 operands split into 3 bf16 pieces, 6 piece products, fp32 accumulation).  NOT the headline and NOT
+            # fp32: its own key, its own dtype, priced both ways.
+            inf3 = {}
+            dt3, tcn3_ms, n3 = clip_leg(B, args.steps, args.warmup, precision="bf16x3", info=inf3)
+            tcn_fl = tcn_flops_per_clip_forward(B * NTU["M"])                # fp32-equivalent FLOPs of the ten temporal convs
+            line["clip_bf16x3"] = {
+                "metric": "clips/sec (ST-GCN clip forward, temporal conv in the opt-in bf16x3 split arithmetic)",
+                "value": round(B * world * args.steps / dt3, 2), "unit": "clips/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                "dtype": "bf16x3-split, f32 accumulate (temporal conv); f32 (graph conv, head)",
+                "speedup_vs_f32": round(dt / dt3, 3),
+                "max_abs_logit_diff_vs_f32": inf3.get("max_abs_diff_vs_f32"), "logit_absmax": inf3.get("logit_absmax"),
+                "tcn_stage": {"avg_launch_ms": round(tcn3_ms / max(1, n3), 4), "launches_timed": n3,
+                              "fp32_equivalent_tflops": round(tcn_fl / 10.0 / (tcn3_ms / 1e3 / max(1, n3)) / 1e12, 2),
+                              "executed_bf16_tflops": round(6 * tcn_fl / 10.0 / (tcn3_ms / 1e3 / max(1, n3)) / 1e12, 2),
+                              "frac_of_bf16_peak": round(6 * tcn_fl / 10.0 / (tcn3_ms / 1e3 / max(1, n3)) / 1e12 / 2500.0, 4),
+                              "note": "6 bf16 MFMA products per fp32 product: executed FLOPs = 6 x the fp32-equivalent; peak 2.5 PFLOP/s dense bf16"},
+                "fp32_path_tcn_stage_avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                "scope": "clip kernels only (csk_tcn_stage_bf16x3); the continual step kernels stay exact fp32 (DESIGN.md)"}
         if use_dist:
             # BASELINE.json configs[4]: batch 8192 over 8 GPUs = 1024 clips per GPU + the RCCL logit all-gather.  Reported
             # beside the 256 / GPU weak-scaling headline (which stays comparable with the N = 1 line); at N = 8 this IS

@@ -43,19 +43,12 @@ class AdaptiveGraphConvolution(GraphConvolution):
         be = torch.cat([sd[f"a_conv.{i}.bias"] for i in range(3)] + [sd[f"b_conv.{i}.bias"] for i in range(3)], 0)
         f["w_embed"] = fold.pack_conv_weight(we.view(6 * inter, ci, 1, 1), torch.ones(6 * inter, dtype=torch.float64))
         f["b_embed"] = fold.pad_vec(be.double())
-        # Continual use: a 1x1 conv has one "tap", i.e. 16 MFMAs per barrier pair of the step kernel.  The channel
-        # axis is therefore cut into g groups that are presented to the kernel as the g taps of a (g x 1) conv over
-        # C_in / g channels -- group r of a channel-major frame (C_in, P) *is* ring slot r of a ring of (C_in / g, P)
-        # frames -- which gives g times longer MFMA runs per chunk.  Same sums, different summation order.
-        g = next(k for k in (8, 4, 2, 1) if ci % (fold.KC * k) == 0 or k == 1)
-        f["embed_groups_host"] = torch.tensor([g], dtype=torch.int32)
-        wg = we.view(6 * inter, g, ci // g).permute(0, 2, 1).unsqueeze(-1)                    # (co, C_in / g, g, 1)
-        f["w_embed_step"] = fold.pack_conv_weight(wg.contiguous(), torch.ones(6 * inter, dtype=torch.float64))
         return f
 
     def _attention(self, E, ops, n_seg, T, V, e_seg_stride, e_chan_stride, seg_per_group=None, e_group_stride=0):
         adj = torch.empty((n_seg, 3, V, V), device=E.device, dtype=torch.float32)
-        rc = native.lib().csk_agcn_attention_f32(native.ptr(E), native.ptr(ops["a_sum"]), native.ptr(adj), n_seg,
+        scratch = torch.empty((n_seg, 3, 4, V, V), device=E.device, dtype=torch.float32) if T > 1 else None
+        rc = native.lib().csk_agcn_attention_f32(native.ptr(E), native.ptr(ops["a_sum"]), native.ptr(adj), native.ptr(scratch), n_seg,
                                                  self.inter_c, T, V, e_seg_stride, e_chan_stride,
                                                  seg_per_group or n_seg, e_group_stride, native.stream_of(E))
         native.check(rc, "csk_agcn_attention_f32")
@@ -67,7 +60,11 @@ class AdaptiveGraphConvolution(GraphConvolution):
         ops = self._packed_ops(x.device)
         n, c, t, v = x.shape
         e_ch = 6 * self.inter_c
-        E = blocks.tcn_stage(x, ops["w_embed"], ops["b_embed"], e_ch, 1, 1, 0, relu=False)       # (N, 6*inter, T, V)
+        # (N, 6*inter, T, V), + 4 floats of slack behind it (csk_agcn_attention_f32 reads whole 16-byte vectors)
+        E = torch.empty((n * e_ch * t * v + 4,), device=x.device, dtype=torch.float32)[: n * e_ch * t * v].view(n, e_ch, t, v)
+        rc = native.lib().csk_conv1x1_f32(native.ptr(x), native.ptr(E), native.ptr(ops["w_embed"]), native.ptr(ops["b_embed"]), n, c,
+                                          e_ch, t, v, c * t * v, t * v, e_ch * t * v, t * v, native.stream_of(x))
+        native.check(rc, "csk_conv1x1_f32")
         adj = self._attention(E, ops, n, t, v, e_ch * t * v, t * v)
         y = torch.empty((n, self.out_channels, t, v), device=x.device, dtype=torch.float32)
         o = dict(ops, ell_val=adj)
@@ -84,13 +81,10 @@ class AdaptiveGraphConvolution(GraphConvolution):
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
         E = torch.empty((n_seg, e_ch, p), device=x.device, dtype=torch.float32)
-        # the 1x1 embedding conv as a (g x 1) conv over channel groups (see _fold): the n_seg block-input slots are a
-        # ring of g * n_seg slots of (C_in / g, P); emission j reads slots g*j .. g*j + g - 1
-        g = int(ops["embed_groups_host"][0])
-        rc = native.lib().csk_tcn_step_f32(native.ptr(x), g * n_seg, g - 1, g, n_seg, native.ptr(ops["w_embed_step"]), None, 0, 0, 0,
-                                           None, native.ptr(ops["b_embed"]), native.ptr(E), n_seg, 0, self.in_channels // g, e_ch,
-                                           p, g, 0, 0, 0, 1, None, native.stream_of(x))
-        native.check(rc, "csk_tcn_step_f32")
+        # the fused 1x1 embedding conv on the channel-major slots: segment = ring slot, frames = skeletons
+        rc = native.lib().csk_conv1x1_f32(native.ptr(x), native.ptr(E), native.ptr(ops["w_embed"]), native.ptr(ops["b_embed"]), n_seg,
+                                          self.in_channels, e_ch, frames, v, x_strides[0], p, e_ch * p, p, native.stream_of(x))
+        native.check(rc, "csk_conv1x1_f32")
         adj = self._attention(E, ops, n_seg * frames, 1, v, v, p, seg_per_group=frames, e_group_stride=e_ch * p)
         o = dict(ops, ell_val=adj)
         # segment = one channel-major frame, adjacency per "frame" of it (= skeleton): index seg * frames + skeleton

@@ -263,11 +263,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
 //     a GCN k-step carries 18 LDS reads + 14 VALU per 12 MFMAs whose latency a third wave per SIMD covers.
 // KCG_ = channels per chunk.
 // ------------------------------------------------------------------------------------------------
-template <int MT, bool CONVRES, int KCG_>
+// PLAIN: the same pipeline as a bare 1 x 1 conv (one "subset" with the identity adjacency, no residual, no ReLU) -- the six
+// a_i / b_i embedding convs of A-GCN fused into one GEMM (models/a_gcn/a_gcn.py:53-59), csk_conv1x1_f32.
+template <int MT, bool CONVRES, int KCG_, bool PLAIN = false>
 __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const GcnParams p) {
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
-    constexpr int R = CONVRES ? 4 : 3;
+    constexpr int R = PLAIN ? 1 : (CONVRES ? 4 : 3);
     constexpr int M4 = MT / 4;
     constexpr int WB = (R * KCG_ * M4 + NTHREADS - 1) / NTHREADS;   // f32x4 of weights per thread per chunk
     constexpr int RPW = KCG_ / (NTHREADS / 64);            // activation rows per wave per chunk
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
             const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;          // subsets 0,1: one entry; subset 2: four
-            const bool have = k < p.ell_cnt[r];
-            const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
+            const bool have = !PLAIN && k < p.ell_cnt[r];
+            const int idx = PLAIN ? 0 : (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
             eoff[ni][e] = fb + (have ? p.ell_src[idx] : 0);
             eval[ni][e] = have ? p.ell_val[idx] : 0.f;
         }
@@ -395,15 +397,19 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
         float b[R][2];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const float x0 = bx[eoff[ni][0]];
-            b[0][ni] = eval[ni][0] * x0;
-            b[1][ni] = eval[ni][1] * bx[eoff[ni][1]];
-            float s2 = eval[ni][2] * bx[eoff[ni][2]];
-            s2 = fmaf(eval[ni][3], bx[eoff[ni][3]], s2);
-            s2 = fmaf(eval[ni][4], bx[eoff[ni][4]], s2);
-            s2 = fmaf(eval[ni][5], bx[eoff[ni][5]], s2);
-            b[2][ni] = s2;
-            if (CONVRES) b[R - 1][ni] = bx[ioff[ni]];
+            if constexpr (PLAIN) {
+                b[0][ni] = bx[ioff[ni]];
+            } else {
+                const float x0 = bx[eoff[ni][0]];
+                b[0][ni] = eval[ni][0] * x0;
+                b[1][ni] = eval[ni][1] * bx[eoff[ni][1]];
+                float s2 = eval[ni][2] * bx[eoff[ni][2]];
+                s2 = fmaf(eval[ni][3], bx[eoff[ni][3]], s2);
+                s2 = fmaf(eval[ni][4], bx[eoff[ni][4]], s2);
+                s2 = fmaf(eval[ni][5], bx[eoff[ni][5]], s2);
+                b[2][ni] = s2;
+                if (CONVRES) b[R - 1][ni] = bx[ioff[ni]];
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const float *rrow = seg_base + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.x_chan_stride;
-                    rv[ni][mi][g] = CONVRES ? 0.f : ld_lane(rrow, lo);
+                    rv[ni][mi][g] = (CONVRES || PLAIN) ? 0.f : ld_lane(rrow, lo);
                 }
             }
         } else {
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
-                    rv[ni][mi][g] = CONVRES ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
+                    rv[ni][mi][g] = (CONVRES || PLAIN) ? 0.f : seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc];
                 }
             }
         }
@@ -496,8 +502,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
     auto finish_half = [&](int mi) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const float v0 = relu_nan(acc[mi][0][g] + bb[mi][g] + rv[0][mi][g]);
-            const float v1 = relu_nan(acc[mi][1][g] + bb[mi][g] + rv[1][mi][g]);
+            float v0 = acc[mi][0][g] + bb[mi][g] + rv[0][mi][g];
+            float v1 = acc[mi][1][g] + bb[mi][g] + rv[1][mi][g];
+            if (!PLAIN) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
             acc[mi][0][g] = __uint_as_float(sw[0]);       // row (g & 3) + 8*(g >> 2), column qb
             acc[mi][1][g] = __uint_as_float(sw[1]);       // row + 4
@@ -602,3 +609,38 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     return (int)hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Bare 1 x 1 conv + bias on the GCN-stage layouts (no adjacency, no residual, no ReLU): the fused a_i / b_i embedding convs
+// of A-GCN (models/a_gcn/a_gcn.py:27-28, 53-59): one GEMM [c_out x c_in] . [c_in x positions] per segment.
+// ------------------------------------------------------------------------------------------------
+extern "C" int csk_conv1x1_f32(const float *x, float *y, const float *w, const float *bias, int n_seg, int c_in, int c_out,
+                               int frames, int V, int64_t x_seg_stride, int64_t x_chan_stride, int64_t y_seg_stride,
+                               int64_t y_chan_stride, void *stream) {
+    if (!x || !y || !w || !bias) CSK_FAIL("conv1x1: null pointer");
+    if (n_seg <= 0 || c_in <= 0 || c_out <= 0 || frames <= 0 || V < 2 || V > 64) CSK_FAIL("conv1x1: bad dims");
+    if ((int64_t)frames * V >= (1 << 26)) CSK_FAIL("conv1x1: frames*V too large for 32-bit position arithmetic");
+    GcnParams p = {};
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ell_src = nullptr; p.ell_val = nullptr;
+    p.ell_cnt[0] = p.ell_cnt[1] = p.ell_cnt[2] = 0; p.ell_w = 1; p.adj_seg_stride = 0;
+    p.x_seg_stride = x_seg_stride; p.x_chan_stride = x_chan_stride; p.y_seg_stride = y_seg_stride; p.y_chan_stride = y_chan_stride;
+    p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.frames = frames; p.V = V; p.R = 1; p.res_mode = CSK_RES_NONE;
+    p.fast_epi = x_chan_stride < (1ll << 27) && y_chan_stride < (1ll << 27);
+    p.no_vec = csk_diag_flag("CSK_GCN_NOVEC");
+    p.vmagic = vmagic_of(V);
+    const bool big = (p.Mpad % 128) == 0;
+    const int MT = big ? 128 : 64, NT = 16384 / MT;
+    const int max_dt = (NT + V - 2) / V;
+    p.ldb = round_up((max_dt + 1) * V, 4);
+    if (p.ldb > (big ? 192 : 320)) CSK_FAIL("conv1x1: activation tile of %d positions exceeds the staged maximum", p.ldb);
+    const int Q = frames * V;
+    p.qtiles = (Q + NT - 1) / NT; p.mtiles = p.Mpad / MT;
+    if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("conv1x1: grid too large");
+    constexpr int KCP = 16;                                // channels per chunk: 32 MFMAs per wave and barrier
+    const size_t lds = 2 * (size_t)(KCP * MT + KCP * p.ldb) * sizeof(float);
+    void (*k)(GcnParams) = big ? gcn_stage_sparse2_kernel<128, false, KCP, true> : gcn_stage_sparse2_kernel<64, false, KCP, true>;
+    if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(p.qtiles * p.mtiles * n_seg), dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

@@ -19,12 +19,13 @@ SIGNATURES = {
     "csk_stream_overlap_probe": [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)],
     "csk_gcn_stage_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _p],
     "csk_tcn_stage_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "csk_conv1x1_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _p],
     "csk_tcn_stage_bf16x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "csk_input_norm_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _p],
     "csk_pool_fc_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "csk_fc_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
     "csk_pool_scaled_f32": [_p, _p, _i, _i, _i, _i, C.c_float, _p],
-    "csk_agcn_attention_f32": [_p, _p, _p, _i, _i, _i, _i, _l, _l, _i, _l, _p],
+    "csk_agcn_attention_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _l, _l, _i, _l, _p],
     "csk_tcn_step_f32": [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _p, _p],
     "csk_co_block_step_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _l, _p],
     "csk_co_spatial_pool_f32": [_p, _p, _i, _i, _i, _l, _p],

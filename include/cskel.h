@@ -103,6 +103,16 @@ int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const 
                       int res_mode, int c_res, int t_res, int res_off, int relu, void *stream);
 
 /*
+ * Bare 1 x 1 conv + bias on the layouts of csk_gcn_stage_f32 (no adjacency, no residual, no ReLU): the six a_i / b_i
+ * embedding convs of AdaptiveGraphConvolution fused into one GEMM, models/a_gcn/a_gcn.py:27-28, 53-59.
+ *  x (n_seg, c_in, frames, V), y (n_seg, c_out, frames, V) with explicit segment / channel strides (elements);
+ *  w packed [1][c_in_pad][c_out_pad], bias [c_out_pad].
+ */
+int csk_conv1x1_f32(const float *x, float *y, const float *w, const float *bias, int n_seg, int c_in, int c_out,
+                    int frames, int V, int64_t x_seg_stride, int64_t x_chan_stride, int64_t y_seg_stride,
+                    int64_t y_chan_stride, void *stream);
+
+/*
  * OPT-IN precision mode "bf16x3" of csk_tcn_stage_f32 (same reference method, models/base.py:302-304 + 376-387; same
  * arguments and layouts except the weights): the 9 x 1 temporal conv and the 1 x 1 residual conv run on the bf16 matrix
  * pipe with every fp32 operand split into three bf16 pieces (h + m + l, 24 significand bits) and the six piece products
@@ -150,8 +160,8 @@ int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *l
 
 /*
  * A-GCN adaptive adjacency, models/a_gcn/a_gcn.py:53-63.  E holds the a_conv / b_conv embeddings of the three
- * subsets (channels [i*inter+k] = a_conv_i, [(3+i)*inter+k] = b_conv_i, biases included; a 1x1 conv produced by
- * csk_tcn_stage_f32 (clip) or csk_tcn_step_f32 (continual)); element (n, ch, t, v) at
+ * subsets (channels [i*inter+k] = a_conv_i, [(3+i)*inter+k] = b_conv_i, biases included; produced by
+ * csk_conv1x1_f32); element (n, ch, t, v) at
  * (n / seg_per_group)*e_group_stride + (n % seg_per_group)*e_seg_stride + ch*e_chan_stride + t*V + v
  * (clip: seg_per_group = n_seg, e_group_stride = 0; continual: a group = one channel-major frame (6*inter, P) of
  * the frames of a launch cycle, a segment = one skeleton of it, e_seg_stride = V, T = 1 -- per-frame attention,
@@ -159,9 +169,12 @@ int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *l
  *     adj[i][v, w] = softmax_v( sum_{k,t} Ea[k,t,v] * Eb[k,t,w] / (inter*T) ) + a_sum[i][v, w],   a_sum = A + graph_attn
  * written as the dense column-wise ELL values ell_val[n][i][w][v] that csk_gcn_stage_f32 consumes with
  * ell_w = V, ell_cnt = {V,V,V}, adj_seg_stride = 3*V*V.
+ * scratch: n_seg * 3 * 4 * V * V floats of partial logits (clip form, T > 1: the K = inter*T contraction is cut into 4
+ * channel ranges per sample, summed in a fixed order); may be NULL for T == 1.  In the clip form E must be readable
+ * 12 bytes past its last element (16-byte loads of the last partial row vector) and 4-byte aligned rows suffice.
  */
-int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, int n_seg, int inter, int T, int V,
-                           int64_t e_seg_stride, int64_t e_chan_stride, int seg_per_group, int64_t e_group_stride,
+int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, float *scratch, int n_seg, int inter, int T,
+                           int V, int64_t e_seg_stride, int64_t e_chan_stride, int seg_per_group, int64_t e_group_stride,
                            void *stream);
 
 /* ------------------------------------------------------------------------------------------------
