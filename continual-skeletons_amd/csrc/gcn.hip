@@ -537,6 +537,237 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
 }
 
 // ------------------------------------------------------------------------------------------------
+// GCN stage for a DENSE PER-SEGMENT adjacency (A-GCN clip form, models/a_gcn/a_gcn.py:62-65): the V x V aggregation itself
+// runs on the matrix pipe.  Per chunk of KC2 channels the aggregation of a tile is the small GEMM
+//     Xa[(frame, channel), (subset, w)] = sum_v  x[channel][frame, v] * adj[subset][v, w]
+// with rows = (frames of the tile) x KC2 channels, columns = 3 V (two or three 32-column blocks), K = V: every (row block,
+// column block) unit is one 32 x 32 accumulator and ceil(V / 2) v_mfma_f32_32x32x2_f32, the units are dealt to the four
+// waves, and the results go to the LDS operand tile Xa of the channel-mixing GEMM.  Against the VALU form of
+// gcn_stage_kernel (3 + KPT LDS reads per 3 KPT FMAs: LDS-issue bound, 1.6 x the sparse kernel's time) this costs
+// +19 % MFMA cycles at V = 18 and frees the vector unit.  Tiles are FRAME-ALIGNED (FT = NT / V whole frames per tile: 126
+// of 128 columns at V = 18) so that every tile has the same row blocks and the x tile starts at the tile's first position.
+// Exact fp32 as everything else (the MFMA is an fmaf chain in k order); only the summation order over v differs from
+// gcn_stage_kernel's (v = 0, 1, 2, ... there as here, but in chunks of two per instruction: the same order).
+// ------------------------------------------------------------------------------------------------
+template <int MT, bool CONVRES, int KC2, int OCC>
+__global__ __launch_bounds__(NTHREADS, OCC) void gcn_stage_dense_kernel(const GcnParams p) {
+    constexpr int NT = 16384 / MT;
+    constexpr int WM = MT / 64;                          // KC2 = channels per chunk, OCC = workgroups per CU
+    constexpr int R = CONVRES ? 4 : 3;
+    constexpr int M4 = MT / 4;
+    constexpr int WB = R * KC2 * M4 / NTHREADS;         // f32x4 of weights per thread and chunk (6 / 8 or 1.5 -> see below)
+    constexpr int WBU = (R * KC2 * M4 + NTHREADS - 1) / NTHREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int V = p.V, FT = p.lds_frames, ldbx = p.ldb;  // frames per tile, padded x row length
+    float *Wl = smem;                                    // [R][KC2][MT]
+    float *Xa = Wl + R * KC2 * MT;                       // [3][KC2][NT]
+    float *Bx = Xa + 3 * KC2 * NT;                       // [KC2][ldbx]
+    float *Ladj = Bx + KC2 * ldbx;                       // [3 V][V]   adj[r][v, w] at (r V + w) V + v
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(wid % p.mtiles) * MT, qt = (int)((wid / p.mtiles) % p.qtiles);
+    const int seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int Q = p.frames * V;
+    const int ta = qt * FT, q0 = ta * V;
+    const int fcnt = min(FT, p.frames - ta);             // frames of this tile
+    const int ncol = fcnt * V;                           // valid columns of this tile
+    (void)WB;
+
+    {   // this segment's adjacency -> LDS (dense column-wise values, include/cskel.h)
+        const float *gv = p.ell_val + (int64_t)seg * p.adj_seg_stride;
+        for (int e = tid; e < 3 * V * V; e += NTHREADS) Ladj[e] = gv[e];
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
+    const float *wbase = p.w + m0;
+    // staging: weights [R][KC2][MT] as 16-byte vectors; x rows as 4-byte-aligned 16-byte vectors, each clamped into its row
+    // (a clamped vector lands at its own -- clamped -- LDS offset, so a partial last vector overlaps its neighbour with
+    // the same values instead of shifting data)
+    f32x4 wv[WBU];
+    constexpr int XV = 2;                                // x vectors per thread and chunk: KC2 rows x <= 256 / 4 ... 
+    const int nvec_row = (ncol + 3) / 4;
+    const int xrow = tid / 32, xv0 = tid % 32;           // 8 rows x 32 vectors per sweep of 256 threads
+    f32x4 xv[XV][2];
+    auto issue = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < WBU; ++u) {
+            const int e = min(u * NTHREADS + tid, R * KC2 * M4 - 1);
+            const int row = e / M4, m4 = e % M4;
+            wv[u] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)((row / KC2) * p.CinPad + c0 + (row % KC2)) * p.Mpad + m4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int kk = xrow + 8 * u;
+            if (kk < KC2) {
+                const float *src = seg_base + (int64_t)min(c0 + kk, p.Cin - 1) * p.x_chan_stride;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int o = min(4 * (xv0 + 32 * h), max(ncol - 4, 0));
+                    xv[u][h] = *reinterpret_cast<const f32x4u *>(src + min(q0 + o, Q - 4));
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < WBU; ++u) *reinterpret_cast<f32x4 *>(Wl + 4 * min(u * NTHREADS + tid, R * KC2 * M4 - 1)) = wv[u];
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int kk = xrow + 8 * u;
+            if (kk < KC2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int o = min(4 * (xv0 + 32 * h), max(ncol - 4, 0));
+                    const int oo = min(q0 + o, Q - 4) - q0;                  // (a tile shorter than 4 positions: Q - 4 < q0 never
+                    *reinterpret_cast<f32x4u *>(Bx + kk * ldbx + max(oo, 0)) = xv[u][h];   //  happens for V >= 4 frames)
+                }
+            }
+        }
+    };
+    (void)nvec_row;
+    // aggregation units of this wave
+    const int RT = (fcnt * KC2 + 31) / 32, CT = (3 * V + 31) / 32, KS2 = (V + 1) / 2;
+    const int offA = wm * 64 + l31;
+    const int off0 = wn * 64 + l31, off1 = off0 + 32;
+
+    issue(0);
+    for (int c0 = 0; c0 < p.CinPad; c0 += KC2) {
+        __syncthreads();                               // previous chunk's reads of Wl / Xa / Bx are done
+        commit();
+        __syncthreads();
+        if (c0 + KC2 < p.CinPad) issue(c0 + KC2);
+        // ---- aggregation on the matrix pipe: unit u = (row block, column block)
+        for (int u = wave; u < RT * CT; u += NTHREADS / 64) {
+            const int rt = u / CT, ct = u - rt * CT;
+            const int row = rt * 32 + l31, col = ct * 32 + l31;          // A operand: row, B operand: column of this lane
+            const int tl = row / KC2, kk = row % KC2;
+            const bool rok = tl < fcnt, cok = col < 3 * V;
+            const float *ax = Bx + kk * ldbx + min(tl, fcnt - 1) * V;
+            const float *bj = Ladj + min(col, 3 * V - 1) * V;
+            f32x16 d;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) d[g] = 0.f;
+            // operands of four k-steps are fetched together, then their MFMAs issue back to back (a rolled one-step loop
+            // exposes the LDS latency of every step: the chain has a single accumulator)
+            for (int s2 = 0; s2 < KS2; s2 += 4) {
+                float a[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int v = 2 * (s2 + j) + kh;
+                    const bool vok = v < V;
+                    const float av = ax[min(v, V - 1)], bv = bj[min(v, V - 1)];
+                    a[j] = (rok && vok) ? av : 0.f;
+                    b[j] = (cok && vok) ? bv : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], d, 0, 0, 0);
+            }
+            // D[row][col]: col = this lane, rows (g & 3) + 8 (g >> 2) + 4 kh -> Xa[subset][channel][frame V + w]
+            const int r = col / V, w = col - r * V;
+            if (cok) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int ro = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * kh;
+                    const int tlo = ro / KC2, kko = ro % KC2;
+                    if (tlo < fcnt) Xa[(r * KC2 + kko) * NT + tlo * V + w] = d[g];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- channel mixing: acc += W[r][kk][rows] x Xa[r][kk][cols]  (+ conv gcn_residual: 4th subset straight from x)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float *wr = Wl + (r * KC2 + kh) * MT + offA;
+            const float *br = (CONVRES && r == 3) ? Bx + kh * ldbx : Xa + (r * KC2 + kh) * NT;
+            const int ldr = (CONVRES && r == 3) ? ldbx : NT;
+#pragma unroll
+            for (int s = 0; s < KC2 / 2; ++s) {
+                const float a0 = wr[2 * s * MT], a1 = wr[2 * s * MT + 32];
+                const float b0 = br[2 * s * ldr + off0], b1 = br[2 * s * ldr + off1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: ReLU(acc + bias + identity residual), scheme of gcn_stage_kernel; columns beyond the tile's frames are dropped
+    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+    const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    const int rbase = m0 + wm * 64;
+    const bool full = p.fast_epi && m0 + MT <= p.Cout;
+    const unsigned kh4 = 4u * (unsigned)kh;
+    const int jb = wn * 64 + lane, qb = q0 + jb;
+    const bool qv = jb < ncol;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        float bb[16], rv[2][16];
+        if (full) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bb[g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const unsigned lo = 4u * (kh4 * (unsigned)p.x_chan_stride + (unsigned)min(q0 + wn * 64 + ni * 32 + l31, Q - 1));
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float *rrow = seg_base + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.x_chan_stride;
+                    rv[ni][g] = ident ? ld_lane(rrow, lo) : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bb[g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int qc = min(q0 + wn * 64 + ni * 32 + l31, Q - 1);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
+                    rv[ni][g] = ident ? seg_base[(int64_t)min(co, p.Cout - 1) * p.x_chan_stride + qc] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float v0 = relu_nan(acc[mi][0][g] + bb[g] + rv[0][g]);
+            const float v1 = relu_nan(acc[mi][1][g] + bb[g] + rv[1][g]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+            acc[mi][0][g] = __uint_as_float(sw[0]);
+            acc[mi][1][g] = __uint_as_float(sw[1]);
+        }
+        if (full) {
+            if (qv) {
+                const unsigned qo = 4u * (unsigned)qb;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float *orow = oseg + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * p.y_chan_stride;
+                    st_lane(orow, qo, acc[mi][0][g]);
+                    st_lane(orow + 4 * p.y_chan_stride, qo, acc[mi][1][g]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
+                if (qv && row0 < p.Cout) oseg[(int64_t)row0 * p.y_chan_stride + qb] = acc[mi][0][g];
+                if (qv && row0 + 4 < p.Cout) oseg[(int64_t)(row0 + 4) * p.y_chan_stride + qb] = acc[mi][1][g];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
@@ -600,6 +831,22 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     }
     // activation staging sweeps per row: whole frames of the tile only (no temporal halo), i.e. < NT + 2 V positions:
     // <= 256 for 128-wide and <= 384 for 256-wide tiles at V <= 64 -- 3-4 / 5-6 sweeps of 64 lanes (all spill-free)
+    // dense per-segment adjacency (A-GCN clip form): aggregation on the matrix pipe, frame-aligned tiles
+    if (p.dense && !p.adj_per_frame && V >= 4 && V <= 32 && NT / V >= 1 && frames * (int64_t)V >= 4 && !csk_diag_flag("CSK_GCN_VALU_AGG")) {
+        const int KC2 = 8;
+        p.lds_frames = NT / V;                                  // FT: whole frames per tile
+        int ldbx = round_up(p.lds_frames * V, 4);
+        if ((ldbx / 4) % 2 == 0) ldbx += 4;                     // row stride = 4 (mod 8) words: the row-block reads are at most 2-way conflicted
+        p.ldb = ldbx;
+        p.qtiles = (frames + p.lds_frames - 1) / p.lds_frames;
+        if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
+        const size_t ldsd = (size_t)(p.R * KC2 * MT + 3 * KC2 * NT + KC2 * ldbx + 3 * V * V) * sizeof(float);
+        void (*kd)(GcnParams) = !big ? (p.R == 4 ? gcn_stage_dense_kernel<64, true, 8, 3> : gcn_stage_dense_kernel<64, false, 8, 3>)
+                                     : (p.R == 4 ? gcn_stage_dense_kernel<128, true, 8, 3> : gcn_stage_dense_kernel<128, false, 8, 3>);
+        if (const int e = csk_ensure_lds((const void *)kd, ldsd)) return e;
+        hipLaunchKernelGGL(kd, dim3(p.qtiles * p.mtiles * n_seg), dim3(NTHREADS), ldsd, (hipStream_t)stream, p);
+        return (int)hipGetLastError();
+    }
     const int nj = (p.ldb + 63) / 64;
     if (nj > (big ? 4 : 6)) CSK_FAIL("gcn_stage: activation tile of %d positions per channel exceeds the staged maximum", p.ldb);
     void (*kern)(GcnParams) = big ? (nj <= 3 ? gcn_stage_kernel<128, 3> : gcn_stage_kernel<128, 4>)

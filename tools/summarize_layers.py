@@ -25,7 +25,7 @@ import workmodel as wm  # noqa: E402
 def short(name):
     for k in ("gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
               "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
-              "agcn_attention_kernel", "tcn_split_stage_kernel", "tcn_split_step_kernel"):
+              "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_stage_dense_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
             return k + t
@@ -33,7 +33,7 @@ def short(name):
 
 
 def klass(name):
-    if "agcn_attention" in name:
+    if "agcn_" in name:
         return "a"
     if "gcn_stage" in name:
         return "g"
@@ -63,7 +63,7 @@ def main():
     a = ap.parse_args()
     V = 18 if a.model == "agcn" else 25
     adaptive = a.model == "agcn"
-    tcn_per_cycle = 20 if adaptive else 10
+    tcn_per_cycle = 10
     files = sorted(glob.glob(os.path.join(a.trace_dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if not files:
         raise SystemExit(f"no kernel_trace.csv under {a.trace_dir}")
@@ -106,19 +106,26 @@ def main():
             k in r["Kernel_Name"] for k in ("co_spatial_pool", "co_window_mean", "fc_kernel", "pool_kernel"))]
         windows.append((int(good[0][0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in path)))
         for c in good:
-            li, tot, oth, seen_g = 0, 0.0, 0.0, False
+            li, tot, oth, seen_a = 0, 0.0, 0.0, False
             for r in c:
                 ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
                 k = klass(r["Kernel_Name"])
                 tot += ms
                 per_kernel[short(r["Kernel_Name"])].append(ms)
-                if adaptive and li < 10 and (k == "a" or (k == "t" and not seen_g)):
-                    per_layer[li]["e" if k == "t" else "a"].append(ms)       # embedding conv / attention of block li
+                if adaptive and li < 10 and (k == "a" or (k == "g" and not seen_a)):
+                    # A-GCN block: embedding conv (the plain-mode graph-conv kernel in front of the attention), attention
+                    # kernels (their durations are summed per block), graph conv, temporal conv
+                    if k == "a":
+                        if seen_a:
+                            per_layer[li]["a"][-1] += ms
+                        else:
+                            per_layer[li]["a"].append(ms)
+                        seen_a = True
+                    else:
+                        per_layer[li]["e"].append(ms)
                     continue
-                if k == "g":
-                    seen_g = True
-                elif k in "tf":
-                    seen_g = False
+                if k in "tf":
+                    seen_a = False
                 if k in "gtf" and li < 10:
                     per_layer[li][k].append(ms)
                     if k in "tf":
