@@ -139,6 +139,28 @@ struct BSplitStage {
             dst[4 * ldb] = __builtin_bit_cast(u32x4, pl);
         }
     }
+    // the same in two steps: the split (vector ALU work) issued in front of a stage's MFMAs, where it runs beside the matrix
+    // pipe, and the LDS writes behind the barrier that frees the tile
+    u32x4 pk[NS4][3];
+    __device__ __forceinline__ void presplit() {
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            bf16x8 ph, pm, pl;
+            split8(v[i], ph, pm, pl);
+            pk[i][0] = __builtin_bit_cast(u32x4, ph);
+            pk[i][1] = __builtin_bit_cast(u32x4, pm);
+            pk[i][2] = __builtin_bit_cast(u32x4, pl);
+        }
+    }
+    __device__ __forceinline__ void commit_pk(u32x4 *__restrict__ Bl, int ldb) const {
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            u32x4 *dst = Bl + h * ldb + loff[i];
+            dst[0] = pk[i][0];
+            dst[2 * ldb] = pk[i][1];
+            dst[4 * ldb] = pk[i][2];
+        }
+    }
 };
 
 // NTAP taps of the staged weights against the activation tile: per tap 12 ds_read_b128 (3 pieces x (2 row + 2 column
@@ -187,10 +209,12 @@ struct SplitCursor {
     }
 };
 
-template <int MT, int NS4>
+// FAST: one kind of three full weight stages per chunk (stride 1, no residual conv) with compile-time stage structure
+template <int MT, int NS4, bool FAST>
 __global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplitParams p) {
     constexpr int WM = MT / 64;
     constexpr int WSZ = TG * 6 * MT;                        // vectors of one weight buffer
+    constexpr bool PRE = FAST && NS4 <= (MT == 128 ? 2 : 3);   // early split of the next tile (where the registers allow it)
     extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
     u32x4 *Wl0 = smem4;                                     // 2 x [TG][3][2][MT]
     u32x4 *Bl = smem4 + 2 * WSZ;                            // [3][2][ldb]
@@ -250,6 +274,34 @@ __global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplit
             issue_b(T1);
         }
         __syncthreads();
+        if constexpr (FAST) {
+            // the common shape (stride 1, no residual conv: one kind of three full stages per chunk), written with
+            // compile-time stage structure: parity of the weight buffers, tap offsets and branches fold away
+            const SplitKind &kd = p.kind[0];
+            const int nchunks = kd.nchunks, nst = nchunks * NSTAGE;
+            const u32x4 *wb = kd.w + m0;
+            const int64_t sstride = (int64_t)TG * 6 * p.Mpad;
+            for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+                for (int s = 0; s < NSTAGE; ++s) {
+                    const int g = c * NSTAGE + s;
+                    u32x4 *cur = Wl0 + (g & 1) * WSZ, *oth = Wl0 + ((g & 1) ^ 1) * WSZ;
+                    if (g + 1 < nst) ws.commit(oth, tid);
+                    if (g + 2 < nst) ws.issue(wb + (g + 2) * sstride, p.Mpad, tid);
+                    if (PRE && s == NSTAGE - 1 && c + 1 < nchunks) bs.presplit();   // next tile's pieces, beside this stage's MFMAs
+                    __builtin_amdgcn_s_setprio(1);
+                    mfma_split_taps<MT, TG>(cur, Bl + s * TG * V, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    __builtin_amdgcn_s_setprio(0);
+                    __syncthreads();
+                }
+                if (c + 1 < nchunks) {
+                    if (PRE) bs.commit_pk(Bl, p.ldb);
+                    else bs.commit(Bl, p.ldb);
+                    if (c + 2 < nchunks) bs.issue(kd.src + (int64_t)seg * kd.seg_stride, kd.C, kd.chan_stride, (c + 2) * KS);
+                    __syncthreads();
+                }
+            }
+        } else {
         int g = 0;
         while (G.valid(p)) {
             const SplitKind &kd = p.kind[G.k];
@@ -283,6 +335,7 @@ __global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplit
             } else if (p.diag & 2) {
                 T1.next_tile(p);
             }
+        }
         }
     }
     // ---- epilogue: + bias (+ identity residual), ReLU, stores -- the scheme of tcn_stage_kernel (scalar row bases + 32-bit
@@ -425,8 +478,11 @@ extern "C" int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const f
     if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage_bf16x3: grid too large");
     dim3 grid(p.qtiles * p.mtiles * n_seg);
     void (*kern)(TcnSplitParams);
-    if (big) kern = ns4 <= 2 ? tcn_split_stage_kernel<128, 2> : tcn_split_stage_kernel<128, 3>;      // (4 sweeps per wave would spill)
-    else kern = ns4 <= 2 ? tcn_split_stage_kernel<64, 2> : ns4 == 3 ? tcn_split_stage_kernel<64, 3> : tcn_split_stage_kernel<64, 4>;
+    const bool fast = p.nkinds == 1 && p.kind[0].nst == NSTAGE && p.kind[0].ntaps == NSTAGE * TG && !p.diag;
+#define CSK_PICKS(MT_, NS_) (fast ? tcn_split_stage_kernel<MT_, NS_, true> : tcn_split_stage_kernel<MT_, NS_, false>)
+    if (big) kern = ns4 <= 2 ? CSK_PICKS(128, 2) : CSK_PICKS(128, 3);      // (4 sweeps per wave would spill)
+    else kern = ns4 <= 2 ? CSK_PICKS(64, 2) : ns4 == 3 ? CSK_PICKS(64, 3) : CSK_PICKS(64, 4);
+#undef CSK_PICKS
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTH2), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
