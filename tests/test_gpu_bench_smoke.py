@@ -39,6 +39,9 @@ def test_bench_line_contract(workload):
     rc = d["roofline_config"]
     assert rc["frac"] == rc["frac_executed"] and rc["frac_alg"] >= rc["frac"] and rc["flops_executed"] <= rc["flops_alg"]
     assert d["ranks_seen"] == 1 and d["collective_backend"] is None
+    if workload in ("clip", "both"):          # the opt-in precision mode is reported under its own key, never as the headline
+        b3 = d["clip_bf16x3"]
+        assert b3["value"] > 0 and "bf16x3" in b3["dtype"] and b3["max_abs_logit_diff_vs_f32"] < 1e-4 and d["dtype"] == "f32"
     if workload == "both":        # BASELINE configs[3] legs carry their own whole-config roofline and CPU baseline
         k = d["agcn_kinetics"]
         for leg, unit in (("agcn_clip", "clips/s"), ("coagcn_online", "frames/s")):

@@ -262,3 +262,67 @@ def test_no_kernel_spills():
     assert len(kernels) >= 30, len(kernels)
     spilling = [(n, int(b)) for n, b in kernels if int(b) != 0]
     assert not spilling, spilling
+
+
+def test_split_weight_packing_reconstructs_the_fp32_weights():
+    """fold.pack_conv_weight_split (operand image of csk_tcn_stage_bf16x3): the three bf16 pieces of every element sum back
+    to the fp32 weight the exact path packs (24 significand bits), taps are grouped by residue class modulo the stride
+    ("kinds", 3 tap slots per weight stage, zero slots behind the last tap), padding channels / rows are zero."""
+    from continual_skeletons_amd import fold
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(70, 20, 9, 1, generator=g)
+    sc = torch.rand(70, generator=g).double() + 0.5
+    w32 = (w.double()[:, :, :, 0] * sc[:, None, None]).float()
+    for stride in (1, 2, 3):
+        img = fold.pack_conv_weight_split(w, sc, stride)
+        assert img.dtype == torch.int16
+        pos = 0
+        for rho in range(stride):
+            taps = list(range(rho, 9, stride))
+            slots = -(-len(taps) // 3) * 3
+            n = 2 * slots * 3 * 2 * 128 * 8                                # [c16 = 2][slots][3][2][Mpad = 128][8]
+            kind = img[pos:pos + n].view(torch.bfloat16).float().view(2, slots, 3, 2, 128, 8)
+            pos += n
+            rec = kind.sum(2).permute(3, 0, 2, 4, 1).reshape(128, 32, slots)   # [co][c][slot]
+            assert torch.equal(rec[:70, :20, : len(taps)], w32[:, :, taps])     # exact: h + m + l == the fp32 value
+            assert float(rec[70:].abs().max()) == 0 and float(rec[:, 20:].abs().max()) == 0
+            assert float(rec[:, :, len(taps):].abs().max() if slots > len(taps) else 0.0) == 0
+        assert pos == img.numel()
+    one = fold.pack_conv_weight_split(torch.randn(8, 5, 1, 1, generator=g), torch.ones(8, dtype=torch.float64), 2)
+    assert one.numel() == 1 * 3 * 3 * 2 * 64 * 8                               # k = 1: one kind, one stage, one tap
+    with pytest.raises(ValueError):
+        fold.pack_conv_weight_split(torch.randn(8, 5, 3, 1), torch.ones(8, dtype=torch.float64))
+
+
+def test_new_entry_points_validate_their_arguments_without_a_gpu():
+    import ctypes as C
+    lib = pkg.native.lib()
+    fake = C.c_void_p(0x1000)
+    assert lib.csk_conv1x1_f32(None, fake, fake, fake, 1, 4, 4, 3, 25, 300, 75, 300, 75, None) == -1
+    assert b"null pointer" in lib.csk_last_error()
+    assert lib.csk_conv1x1_f32(fake, fake, fake, fake, 1, 4, 4, 3, 70, 840, 210, 840, 210, None) == -1
+    assert b"bad dims" in lib.csk_last_error()
+    # the clip form of the attention (T > 1) needs its partial-logit scratch
+    assert lib.csk_agcn_attention_f32(fake, fake, fake, None, 2, 4, 6, 18, 100, 10, 2, 0, None) == -1
+    assert b"scratch" in lib.csk_last_error()
+    # bf16x3 stage: the 9-tap conv only, stride <= 4, 16-byte aligned operand images
+    args = dict(y=fake, w=fake, xr=None, wr=None, b=fake, o=fake)
+    def split(k=9, stride=1, w=fake):
+        return lib.csk_tcn_stage_bf16x3(args["y"], w, args["xr"], args["wr"], args["b"], args["o"], 1, 16, 16, 20, 25, k, stride, 4, 0, 0,
+                                        0, 0, 1, None)
+    assert split(k=3) == -1 and b"9 x 1" in lib.csk_last_error()
+    assert split(stride=5) == -1 and b"stride" in lib.csk_last_error()
+    assert split(w=C.c_void_p(0x1008)) == -1 and b"16-byte aligned" in lib.csk_last_error()
+
+
+def test_set_precision_marks_blocks_and_refolds():
+    m = pkg.StGcn(pkg.ntu_graph().A)
+    assert all(b.precision == "f32" for b in m.layers.values())
+    pkg.set_precision(m, "bf16x3")
+    assert all(b.precision == "bf16x3" for b in m.layers.values())
+    ops = m.layers["layer5"]._fold()                                  # stride-2 block with a conv residual
+    assert ops["w_split"].dtype == torch.int16 and ops["w_res_split"] is not None and ops["w"].dtype == torch.float32
+    pkg.set_precision(m, "f32")
+    assert m.layers["layer5"]._fold()["w_split"] is None
+    with pytest.raises(ValueError):
+        pkg.set_precision(m, "fp16")
