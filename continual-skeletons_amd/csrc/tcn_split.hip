@@ -25,27 +25,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int KS = 16;          // channels per K step / chunk of the split kernels
 
-// One "kind" of K-loop work: a conv over `ntaps` taps that are `fs` source frames apart, on 16-channel chunks of one
-// source tensor.  A stride-s temporal conv is s kinds (taps r = rho, rho + s, ... read only the source frames of one
-// residue class: DE-INTERLEAVED in the LDS tile they form a stride-1 conv, so a tile never holds frames a tap set does not
-// use and a tap is a shift of V positions for every stride); the 1 x 1 strided residual conv is one more kind (one tap).
-//   tile frame j  <->  source frame  stride * ta + foff + fs * j,   j < (tb - ta) + ntaps      (ta..tb: output frames of the tile)
-//   weights: [chunk][nst * 3 tap slots][3 pieces][2 halves][Mpad] 16-byte vectors, zero slots behind the last tap
-static constexpr int MAXKINDS = 5;
-struct SplitKind {
-    const float *src;
-    const u32x4 *w;
-    int64_t seg_stride, chan_stride;
-    int C, nchunks, T, fs, foff, ntaps, nst;
-};
-
+// Stride: a stride-s temporal conv reads, for tap r, the source frames s t + r - pad: the taps of one residue class
+// rho = r mod s read ONE de-interleaved set of frames (s t' + rho - pad), in which consecutive taps are one frame apart --
+// a stride-1 conv.  The activation tile therefore holds the classes side by side, each de-interleaved,
+//     [ class 0: (tb - ta) + n_0 frames | class 1: (tb - ta) + n_1 frames | ... ]     (n_rho taps in class rho)
+// the weights are packed class-major (taps 0, s, 2s, ..., then 1, 1 + s, ...: fold.pack_conv_weight_split), and a tap is
+// again a pure address shift -- (frame base of its class + its index in the class) * V -- for every stride: three weight
+// stages of three taps per 16-channel chunk whatever the stride, no frame a tap set does not use, no bank conflicts from
+// strided frame selection.
 struct TcnSplitParams {
-    SplitKind kind[MAXKINDS];
-    int nkinds;
-    const float *xres, *bias;     // identity residual source, folded bias
+    const float *y, *xres, *bias;
+    const u32x4 *w, *wres;        // packed split weights (fold.pack_conv_weight_split): [chunk][9 | 3 tap slots][3][2][Mpad] vectors of 8 bf16
     float *out;
-    int Cout, Mpad, Tout, V, stride;
-    int res_mode, Cres, Tres, res_off, relu, ldb;
+    int C, nchunks, Tin, Cout, Mpad, Tout, V, stride, pad;
+    int ncls, ntap_cls[4];        // residue classes of the taps and their sizes
+    int res_mode, Cres, nchunks_res, Tres, res_off, relu, ldb;
     unsigned vmagic, mtiles, qtiles;
     int nt, fast_epi;
     int diag;   // CSK_DIAG + CSK_SPLIT_SKIP=<bits>: 1 weight staging, 2 activation staging, 4 MFMAs, 8 barriers skipped in the K loop (timing experiments)
@@ -101,13 +95,24 @@ struct BSplitStage {
     unsigned goff[NS4], loff[NS4], valid;
     int h;
     float v[NS4][8];
-    __device__ __forceinline__ void setup(int f0, int fs, int nframes, int T, int V, unsigned vmagic, int lane, int wave) {
+    // tile position j -> (class, frame in class, joint) -> source position; classes: ncls sets of (dt + ntap[rho]) frames,
+    // source frame of tile frame jf of class rho = fbase + rho + fstep * (jf - first frame of the class)
+    __device__ __forceinline__ void setup(int fbase, int fstep, int dt, int ncls, const int (&ntap)[4], int T, int V, unsigned vmagic,
+                                          int lane, int wave) {
         h = wave & 1;
         valid = 0;
+        int total = 0;
+        for (int r = 0; r < ncls; ++r) total += dt + ntap[r];
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
-            const int j = min(((wave >> 1) + 4 * i) * 64 + lane, nframes * V - 1);      // tile position
-            const int jf = div_magic(j, vmagic), f = f0 + fs * jf;
+            const int j = min(((wave >> 1) + 4 * i) * 64 + lane, total * V - 1);        // tile position
+            const int jf = div_magic(j, vmagic);
+            int cls = 0, fb = 0, acc = 0;
+            for (int r = 0; r < ncls; ++r) {
+                if (jf >= acc) { cls = r; fb = acc; }
+                acc += dt + ntap[r];
+            }
+            const int f = fbase + cls + fstep * (jf - fb);
             goff[i] = (unsigned)(min(max(f, 0), T - 1) * V + (j - jf * V));
             loff[i] = (unsigned)j;
             valid |= (f >= 0 && f < T) ? (1u << i) : 0u;
@@ -167,12 +172,12 @@ struct BSplitStage {
 // blocks)) and 24 MFMAs (6 piece products x 2 x 2 blocks), small products first.  Unrolled over the taps of a stage so
 // that the scheduler can run a tap's fragment reads under the previous tap's MFMAs.
 template <int MT, int NTAP>
-__device__ __forceinline__ void mfma_split_taps(const u32x4 *__restrict__ Wl, const u32x4 *__restrict__ Bl, int ldb, int tapB,
+__device__ __forceinline__ void mfma_split_taps(const u32x4 *__restrict__ Wl, const u32x4 *__restrict__ Bl, int ldb, const int *toff,
                                                 int offA, int off0, int off1, int kh, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
         const u32x4 *wr = Wl + (t * 6 + kh) * MT + offA;
-        const u32x4 *br = Bl + kh * ldb + t * tapB;
+        const u32x4 *br = Bl + kh * ldb + toff[t];
         bf16x8 a[3][2], b[3][2];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
@@ -192,29 +197,11 @@ __device__ __forceinline__ void mfma_split_taps(const u32x4 *__restrict__ Wl, co
     }
 }
 
-// cursor over the K loop's (kind, chunk, stage) triples -- all wave-uniform scalars
-struct SplitCursor {
-    int k, c, s;
-    __device__ __forceinline__ bool valid(const TcnSplitParams &p) const { return k < p.nkinds; }
-    __device__ __forceinline__ void next_stage(const TcnSplitParams &p) {
-        if (++s == p.kind[k].nst) { s = 0; next_tile(p); }
-    }
-    __device__ __forceinline__ void next_tile(const TcnSplitParams &p) {
-        s = 0;
-        if (++c == p.kind[k].nchunks) { c = 0; ++k; }
-    }
-    __device__ __forceinline__ const u32x4 *wptr(const TcnSplitParams &p, int m0) const {
-        const SplitKind &kd = p.kind[k];
-        return kd.w + ((int64_t)(c * kd.nst + s) * TG * 6) * p.Mpad + m0;
-    }
-};
-
-// FAST: one kind of three full weight stages per chunk (stride 1, no residual conv) with compile-time stage structure
-template <int MT, int NS4, bool FAST>
+template <int MT, int NS4>
 __global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplitParams p) {
     constexpr int WM = MT / 64;
     constexpr int WSZ = TG * 6 * MT;                        // vectors of one weight buffer
-    constexpr bool PRE = FAST && NS4 <= (MT == 128 ? 2 : 3);   // early split of the next tile (where the registers allow it)
+    constexpr bool PRE = NS4 <= (MT == 128 ? 2 : 3);        // early split of the next tile (where the registers allow it)
     extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
     u32x4 *Wl0 = smem4;                                     // 2 x [TG][3][2][MT]
     u32x4 *Bl = smem4 + 2 * WSZ;                            // [3][2][ldb]
@@ -228,12 +215,27 @@ __global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplit
     const int V = p.V, Q = p.Tout * V;
     const int qend = min(q0 + p.nt, Q);
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
+    const int dt = tb - ta;
 
-    int off[2];                                             // this lane's two columns inside the (de-interleaved) tile
+    int off[2];                                             // this lane's two columns inside a class of the tile
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int q = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
         off[ni] = q - ta * V;
+    }
+    // LDS offset of tap t (class-major order): (first frame of its class + index in the class) * V -- wave-uniform scalars
+    int toff[NSTAGE * TG];
+#pragma unroll
+    for (int t = 0; t < NSTAGE * TG; ++t) {                 // (static indices only: a runtime-indexed array would live in scratch)
+        int rem = t, fb = 0, o = 0;
+        bool done = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = p.ntap_cls[r];
+            if (!done && rem < n) { o = (fb + rem) * V; done = true; }
+            if (!done) { rem -= n; fb += dt + n; }
+        }
+        toff[t] = o;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -246,96 +248,65 @@ __global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplit
 
     WSplitStage<MT> ws;
     BSplitStage<NS4> bs;
-    // ---- K loop: a flat sequence of weight stages g (3 tap slots each); Wl[g & 1] holds stage g, the registers hold stage
-    // g + 1 until it is committed in front of stage g's MFMAs, stage g + 2 is then issued.  The activation tile of the
-    // current (kind, chunk) sits in Bl, the next tile's values are in flight in registers.
+    // ---- phase 1: the 9-tap conv.  Flat sequence of weight stages g = 3 c + s (3 taps each); Wl[g & 1] holds stage g, the
+    // registers hold stage g + 1 until it is committed in front of stage g's MFMAs, stage g + 2 is then issued.  The
+    // activation tile of chunk c sits in Bl, chunk c + 1 is in flight in registers (split beside the last stage's MFMAs).
     {
-        auto setup_b = [&](int k) {
-            const SplitKind &kd = p.kind[k];
-            bs.setup(p.stride * ta + kd.foff, kd.fs, (tb - ta) + kd.ntaps, kd.T, V, p.vmagic, lane, wave);
-        };
-        auto issue_b = [&](const SplitCursor &t) {
-            const SplitKind &kd = p.kind[t.k];
-            bs.issue(kd.src + (int64_t)seg * kd.seg_stride, kd.C, kd.chan_stride, t.c * KS);
-        };
-        SplitCursor G{0, 0, 0}, G1{0, 0, 0}, G2{0, 0, 0}, T1{0, 0, 0};
-        G1.next_stage(p);
-        G2.next_stage(p); G2.next_stage(p);
-        T1.next_tile(p);
-        ws.issue(G.wptr(p, m0), p.Mpad, tid);
-        setup_b(0);
-        issue_b(G);
+        const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V;
+        const int64_t cs = (int64_t)p.Tin * V;
+        const int nchunks = p.nchunks, nst = nchunks * NSTAGE;
+        const u32x4 *wb = p.w + m0;
+        const int64_t sstride = (int64_t)TG * 6 * p.Mpad;
+        bs.setup(p.stride * ta - p.pad, p.stride, dt, p.ncls, p.ntap_cls, p.Tin, V, p.vmagic, lane, wave);
+        ws.issue(wb, p.Mpad, tid);
+        bs.issue(seg_base, p.C, cs, 0);
         ws.commit(Wl0, tid);
         bs.commit(Bl, p.ldb);
-        if (G1.valid(p)) ws.issue(G1.wptr(p, m0), p.Mpad, tid);
-        int bkind = 0;
-        if (T1.valid(p)) {
-            if (T1.k != bkind) { bkind = T1.k; setup_b(bkind); }
-            issue_b(T1);
-        }
+        if (nst > 1) ws.issue(wb + sstride, p.Mpad, tid);
+        if (nchunks > 1) bs.issue(seg_base, p.C, cs, KS);
         __syncthreads();
-        if constexpr (FAST) {
-            // the common shape (stride 1, no residual conv: one kind of three full stages per chunk), written with
-            // compile-time stage structure: parity of the weight buffers, tap offsets and branches fold away
-            const SplitKind &kd = p.kind[0];
-            const int nchunks = kd.nchunks, nst = nchunks * NSTAGE;
-            const u32x4 *wb = kd.w + m0;
-            const int64_t sstride = (int64_t)TG * 6 * p.Mpad;
-            for (int c = 0; c < nchunks; ++c) {
+        for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
-                for (int s = 0; s < NSTAGE; ++s) {
-                    const int g = c * NSTAGE + s;
-                    u32x4 *cur = Wl0 + (g & 1) * WSZ, *oth = Wl0 + ((g & 1) ^ 1) * WSZ;
-                    if (g + 1 < nst) ws.commit(oth, tid);
-                    if (g + 2 < nst) ws.issue(wb + (g + 2) * sstride, p.Mpad, tid);
-                    if (PRE && s == NSTAGE - 1 && c + 1 < nchunks) bs.presplit();   // next tile's pieces, beside this stage's MFMAs
-                    __builtin_amdgcn_s_setprio(1);
-                    mfma_split_taps<MT, TG>(cur, Bl + s * TG * V, p.ldb, V, offA, off[0], off[1], kh, acc);
-                    __builtin_amdgcn_s_setprio(0);
-                    __syncthreads();
-                }
-                if (c + 1 < nchunks) {
-                    if (PRE) bs.commit_pk(Bl, p.ldb);
-                    else bs.commit(Bl, p.ldb);
-                    if (c + 2 < nchunks) bs.issue(kd.src + (int64_t)seg * kd.seg_stride, kd.C, kd.chan_stride, (c + 2) * KS);
-                    __syncthreads();
-                }
-            }
-        } else {
-        int g = 0;
-        while (G.valid(p)) {
-            const SplitKind &kd = p.kind[G.k];
-            const int nst = kd.nst;
-            for (int s = 0; s < nst; ++s) {
+            for (int s = 0; s < NSTAGE; ++s) {
+                const int g = c * NSTAGE + s;
                 u32x4 *cur = Wl0 + (g & 1) * WSZ, *oth = Wl0 + ((g & 1) ^ 1) * WSZ;
-                if (G1.valid(p) && !(p.diag & 1)) ws.commit(oth, tid);     // stage g + 1 (loaded during stage g - 1)
-                if (G2.valid(p) && !(p.diag & 1)) ws.issue(G2.wptr(p, m0), p.Mpad, tid);
-                const int ntap = min(TG, kd.ntaps - s * TG);
-                const u32x4 *bl = Bl + s * TG * V;
+                if (g + 1 < nst && !(p.diag & 1)) ws.commit(oth, tid);
+                if (g + 2 < nst && !(p.diag & 1)) ws.issue(wb + (g + 2) * sstride, p.Mpad, tid);
+                if (PRE && s == NSTAGE - 1 && c + 1 < nchunks) bs.presplit();      // next tile's pieces, beside this stage's MFMAs
                 __builtin_amdgcn_s_setprio(1);
-                if (!(p.diag & 4)) {
-                    if (ntap == 3) mfma_split_taps<MT, 3>(cur, bl, p.ldb, V, offA, off[0], off[1], kh, acc);
-                    else
-                        for (int t = 0; t < ntap; ++t)
-                            mfma_split_taps<MT, 1>(cur + t * 6 * MT, bl + t * V, p.ldb, V, offA, off[0], off[1], kh, acc);
-                }
+                if (!(p.diag & 4)) mfma_split_taps<MT, TG>(cur, Bl, p.ldb, toff + s * TG, offA, off[0], off[1], kh, acc);
                 __builtin_amdgcn_s_setprio(0);
-                if (!(p.diag & 8)) __syncthreads();                        // stage g's reads done, stage g + 1's weights visible
-                G.next_stage(p); G1.next_stage(p); G2.next_stage(p);
-                ++g;
-            }
-            if (T1.valid(p) && !(p.diag & 2)) {                            // tile boundary: the next activation tile
-                bs.commit(Bl, p.ldb);
-                T1.next_tile(p);
-                if (T1.valid(p)) {
-                    if (T1.k != bkind) { bkind = T1.k; setup_b(bkind); }
-                    issue_b(T1);
-                }
                 if (!(p.diag & 8)) __syncthreads();
-            } else if (p.diag & 2) {
-                T1.next_tile(p);
+            }
+            if (c + 1 < nchunks && !(p.diag & 2)) {
+                if (PRE) bs.commit_pk(Bl, p.ldb);
+                else bs.commit(Bl, p.ldb);
+                if (c + 2 < nchunks) bs.issue(seg_base, p.C, cs, (c + 2) * KS);
+                if (!(p.diag & 8)) __syncthreads();
             }
         }
+    }
+    // ---- phase 2: 1 x 1 strided residual conv over the block input (models/base.py:372-374): one tap per 16-channel chunk
+    if (p.res_mode == CSK_RES_CONV) {
+        const float *seg_base = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
+        const int64_t cs = (int64_t)p.Tres * V;
+        const u32x4 *wb = p.wres + m0;
+        const int64_t sstride = (int64_t)TG * 6 * p.Mpad;      // one stage (tap 0 + two zero slots) per chunk
+        const int one[4] = {1, 0, 0, 0};
+        const int tz[1] = {0};
+        bs.setup(p.stride * ta + p.res_off, p.stride, dt, 1, one, p.Tres, V, p.vmagic, lane, wave);
+        ws.issue(wb, p.Mpad, tid);
+        bs.issue(seg_base, p.Cres, cs, 0);
+        for (int c = 0; c < p.nchunks_res; ++c) {
+            ws.commit(Wl0, tid);                       // (phase 1 / the previous chunk ended with a barrier)
+            bs.commit(Bl, p.ldb);
+            __syncthreads();
+            if (c + 1 < p.nchunks_res) {
+                ws.issue(wb + (c + 1) * sstride, p.Mpad, tid);
+                bs.issue(seg_base, p.Cres, cs, (c + 1) * KS);
+            }
+            mfma_split_taps<MT, 1>(Wl0, Bl, p.ldb, tz, offA, off[0], off[1], kh, acc);
+            __syncthreads();
         }
     }
     // ---- epilogue: + bias (+ identity residual), ReLU, stores -- the scheme of tcn_stage_kernel (scalar row bases + 32-bit
@@ -421,7 +392,7 @@ extern "C" int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const f
     if (!y || !w_split || !bias || !out) CSK_FAIL("tcn_stage_bf16x3: null pointer");
     if (n_seg <= 0 || c <= 0 || c_out <= 0 || t_in <= 0 || V < 2 || V > 64) CSK_FAIL("tcn_stage_bf16x3: bad dims");
     if (k != 9) CSK_FAIL("tcn_stage_bf16x3: the split kernel is built for the 9 x 1 temporal conv (k = %d); use csk_tcn_stage_f32", k);
-    if (stride < 1 || stride > MAXKINDS - 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage_bf16x3: bad stride/pad (stride <= %d)", MAXKINDS - 1);
+    if (stride < 1 || stride > 4 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage_bf16x3: bad stride/pad (stride <= 4)");
     if (t_in + 2 * pad < k) CSK_FAIL("tcn_stage_bf16x3: t_in too short for kernel");
     const int t_out = (t_in + 2 * pad - k) / stride + 1;
     if (res_mode != CSK_RES_NONE) {
@@ -433,56 +404,40 @@ extern "C" int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const f
     if ((int64_t)t_in * V >= (1 << 26)) CSK_FAIL("tcn_stage_bf16x3: T*V too large for 32-bit position arithmetic");
     if (((uintptr_t)w_split | (uintptr_t)(w_res_split ? w_res_split : w_split)) & 15) CSK_FAIL("tcn_stage_bf16x3: packed weights must be 16-byte aligned");
     TcnSplitParams p;
-    p.xres = x_res ? x_res : y; p.bias = bias; p.out = out;
-    p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT); p.Tout = t_out; p.V = V; p.stride = stride;
-    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu;
+    p.y = y; p.w = (const u32x4 *)w_split; p.xres = x_res ? x_res : y; p.wres = (const u32x4 *)w_res_split; p.bias = bias; p.out = out;
+    p.C = c; p.nchunks = round_up(c, KS) / KS; p.Tin = t_in; p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT); p.Tout = t_out;
+    p.V = V; p.stride = stride; p.pad = pad;
+    p.ncls = stride < k ? stride : k;
+    for (int r = 0; r < 4; ++r) p.ntap_cls[r] = r < p.ncls ? (k - r + stride - 1) / stride : 0;
+    p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.nchunks_res = round_up(p.Cres, KS) / KS;
+    p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu;
     p.vmagic = vmagic_of(V);
     p.fast_epi = (int64_t)p.Tres * V < (1ll << 27) && (int64_t)t_out * V < (1ll << 27);
     p.diag = csk_diag_int("CSK_SPLIT_SKIP");
-    // kinds: one per residue class of the taps modulo the stride (fold.pack_conv_weight_split lays the weights out in
-    // this order, back to back), then the residual conv
-    const int nch = round_up(c, KS) / KS;
-    p.nkinds = 0;
-    const u32x4 *wp = (const u32x4 *)w_split;
-    for (int rho = 0; rho < stride && rho < k; ++rho) {
-        SplitKind &kd = p.kind[p.nkinds++];
-        kd.src = y; kd.w = wp; kd.seg_stride = (int64_t)c * t_in * V; kd.chan_stride = (int64_t)t_in * V;
-        kd.C = c; kd.nchunks = nch; kd.T = t_in; kd.fs = stride; kd.foff = rho - pad;
-        kd.ntaps = (k - rho + stride - 1) / stride; kd.nst = (kd.ntaps + TG - 1) / TG;
-        wp += (int64_t)nch * kd.nst * TG * 6 * p.Mpad;
-    }
-    if (res_mode == CSK_RES_CONV) {
-        SplitKind &kd = p.kind[p.nkinds++];
-        kd.src = x_res; kd.w = (const u32x4 *)w_res_split; kd.seg_stride = (int64_t)c_res * t_res * V; kd.chan_stride = (int64_t)t_res * V;
-        kd.C = c_res; kd.nchunks = round_up(c_res, KS) / KS; kd.T = t_res; kd.fs = stride; kd.foff = res_off; kd.ntaps = 1; kd.nst = 1;
-    }
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 32768 / MT;
-    // a tile stages (frames spanned + 9) * V positions per 16-byte row, whatever the stride (frames are de-interleaved): at
-    // most 16 (64-row tiles) / 12 (128-row tiles) x 64 positions (4 / 3 sweeps per wave), and the tile must fit the CU's LDS next to the two weight buffers; more
-    // joints than that narrow the tile -- never the case for the skeleton shapes (V <= 25: 500 / 752 positions)
+    // a tile stages (stride * frames spanned + 9) * V positions per 16-byte row: at most 16 (64-row tiles) / 16 (128-row
+    // tiles) x 64 positions (4 sweeps per wave), and the tile must fit the CU's LDS next to the two weight buffers; longer
+    // spans (stride 3, many joints) narrow the tile -- never the case for the skeleton shapes
     const size_t wl = (size_t)2 * TG * 6 * MT * 16;
     p.nt = NT;
     for (;;) {
         const int max_dt = (p.nt + V - 2) / V;
-        p.ldb = round_up((max_dt + k) * V, 4);
-        if (((p.ldb + 63) / 64 <= (big ? 12 : 16) && wl + (size_t)6 * p.ldb * 16 <= 160 * 1024) || p.nt == 1) break;
+        p.ldb = round_up((stride * max_dt + k) * V, 4);
+        if (((p.ldb + 63) / 64 <= 16 && wl + (size_t)6 * p.ldb * 16 <= 160 * 1024) || p.nt == 1) break;
         p.nt = p.nt > 16 ? p.nt - 16 : 1;
     }
     const int nj = (p.ldb + 63) / 64;
     const size_t lds = wl + (size_t)6 * p.ldb * 16;
-    if (nj > (big ? 12 : 16) || lds > 160 * 1024) CSK_FAIL("tcn_stage_bf16x3: activation tile of %d positions exceeds the staged maximum", p.ldb);
+    if (nj > 16 || lds > 160 * 1024) CSK_FAIL("tcn_stage_bf16x3: activation tile of %d positions exceeds the staged maximum", p.ldb);
     const int ns4 = (nj + 3) / 4;
     const int Q = t_out * V;
     p.qtiles = (Q + p.nt - 1) / p.nt; p.mtiles = p.Mpad / MT;
     if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage_bf16x3: grid too large");
     dim3 grid(p.qtiles * p.mtiles * n_seg);
     void (*kern)(TcnSplitParams);
-    const bool fast = p.nkinds == 1 && p.kind[0].nst == NSTAGE && p.kind[0].ntaps == NSTAGE * TG && !p.diag;
-#define CSK_PICKS(MT_, NS_) (fast ? tcn_split_stage_kernel<MT_, NS_, true> : tcn_split_stage_kernel<MT_, NS_, false>)
-    if (big) kern = ns4 <= 2 ? CSK_PICKS(128, 2) : CSK_PICKS(128, 3);      // (4 sweeps per wave would spill)
-    else kern = ns4 <= 2 ? CSK_PICKS(64, 2) : ns4 == 3 ? CSK_PICKS(64, 3) : CSK_PICKS(64, 4);
-#undef CSK_PICKS
+    if (big) kern = ns4 <= 2 ? tcn_split_stage_kernel<128, 2> : ns4 == 3 ? tcn_split_stage_kernel<128, 3> : tcn_split_stage_kernel<128, 4>;
+    else kern = ns4 <= 2 ? tcn_split_stage_kernel<64, 2> : ns4 == 3 ? tcn_split_stage_kernel<64, 3> : tcn_split_stage_kernel<64, 4>;
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTH2), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -48,29 +48,24 @@ def split3_bf16(w32: torch.Tensor):
 
 def pack_conv_weight_split(weight: torch.Tensor, scale: torch.Tensor, stride: int = 1) -> torch.Tensor:
     """(C_out, C_in, K, 1) conv weight * per-output scale -> the operand image of the bf16x3 split kernels
-    (include/cskel.h, csk_tcn_stage_bf16x3), an int16 tensor of bf16 bit patterns.
-
-    A stride-s conv is laid out as s "kinds", one per residue class rho of the taps (r = rho, rho + s, ...: the taps that
-    read the same de-interleaved set of source frames), back to back; a kind is
-        [C_in_pad / 16][nst * 3 tap slots][3 pieces][2 channel halves][C_out_pad][8 channels]
-    with nst = ceil(n_taps / 3) weight stages of 3 tap slots (zero slots behind the last tap); element
-    [c16][slot][pc][h][co][j] = piece pc of W'[co, 16 c16 + 8 h + j, rho + s * slot].  K = 1 (the residual conv) is one
-    kind with one tap.  The pieces are taken from the SAME fp32 value the exact-fp32 path packs (fp64 fold, one rounding)."""
+    (include/cskel.h, csk_tcn_stage_bf16x3), an int16 tensor of bf16 bit patterns indexed
+        [C_in_pad / 16][tap slots][3 pieces][2 channel halves][C_out_pad][8 channels]
+    element [c16][slot][pc][h][co][j] = piece pc of W'[co, 16 c16 + 8 h + j, tap(slot)].  K = 9: nine slots in CLASS-MAJOR
+    tap order -- taps 0, s, 2s, ... then 1, 1 + s, ... for stride s (the taps of a residue class read one de-interleaved
+    set of source frames; for s = 1 the natural order).  K = 1 (the residual conv): three slots, tap 0 and two zero slots.
+    The pieces are taken from the SAME fp32 value the exact-fp32 path packs (fp64 fold, one rounding to fp32)."""
     co, ci, k, _ = weight.shape
     if k not in (1, 9):
         raise ValueError(f"split weights are built for the 9 x 1 temporal conv and the 1 x 1 residual conv, got k = {k}")
     w32 = (weight.double()[:, :, :, 0] * scale[:, None, None]).float()            # (co, ci, k), as pack_conv_weight
     cpad, mpad = _ceil_to(ci, SPLIT_KS), _ceil_to(co, MT)
-    kinds = []
-    for rho in range(min(stride if k > 1 else 1, k)):
-        taps = list(range(rho, k, stride if k > 1 else 1))
-        slots = _ceil_to(len(taps), 3)
-        full = torch.zeros((mpad, cpad, slots), dtype=torch.float32)
-        full[:co, :ci, : len(taps)] = w32[:, :, taps]
-        pieces = torch.stack([p.view(torch.int16) for p in split3_bf16(full)], 0)        # (3, mpad, cpad, slots)
-        out = pieces.view(3, mpad, cpad // SPLIT_KS, 2, 8, slots).permute(2, 5, 0, 3, 1, 4)  # [c16][slot][pc][h][co][j]
-        kinds.append(out.contiguous().reshape(-1))
-    return torch.cat(kinds).contiguous()
+    taps = [r for rho in range(min(stride, k)) for r in range(rho, k, stride)] if k > 1 else [0]
+    slots = _ceil_to(len(taps), 3)
+    full = torch.zeros((mpad, cpad, slots), dtype=torch.float32)
+    full[:co, :ci, : len(taps)] = w32[:, :, taps]
+    pieces = torch.stack([p.view(torch.int16) for p in split3_bf16(full)], 0)        # (3, mpad, cpad, slots)
+    out = pieces.view(3, mpad, cpad // SPLIT_KS, 2, 8, slots).permute(2, 5, 0, 3, 1, 4)  # [c16][slot][pc][h][co][j]
+    return out.contiguous().reshape(-1)
 
 
 def pad_vec(v: torch.Tensor) -> torch.Tensor:

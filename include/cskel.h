@@ -119,11 +119,10 @@ int csk_conv1x1_f32(const float *x, float *y, const float *w, const float *bias,
  * of order <= 2 accumulated in fp32 -- fp32-GRADE results (measured max error vs the oracle: profiles/r03_parity_report.json),
  * not the exact fp32 arithmetic of csk_tcn_stage_f32.  Never selected implicitly: blocks.set_precision(module, "bf16x3").
  *  w_split      packed split weights of the (k = 9) conv, BN scale folded: 16-byte vectors of 8 bf16 (8 consecutive
- *               input channels).  One "kind" per residue class rho < stride of the taps (r = rho, rho + stride, ...: they
- *               read one de-interleaved set of source frames), back to back; a kind is indexed
- *               [c_pad / 16][nst * 3 tap slots][3 pieces][2 channel halves][c_out_pad], nst = ceil(n_taps / 3), zero
- *               slots behind the last tap (fold.pack_conv_weight_split)
- *  w_res_split  the same for the 1 x 1 residual conv: one kind, one tap, [c_res_pad / 16][3][3][2][c_out_pad], or NULL
+ *               input channels) indexed [c_pad / 16][9 tap slots][3 pieces][2 channel halves][c_out_pad], the taps in
+ *               CLASS-MAJOR order (0, s, 2s, ..., 1, 1 + s, ... for stride s: the taps of a residue class read one
+ *               de-interleaved set of source frames); fold.pack_conv_weight_split
+ *  w_res_split  the same for the 1 x 1 residual conv: [c_res_pad / 16][3 slots: tap 0, zero, zero][3][2][c_out_pad], or NULL
  *  k            must be 9; stride <= 4
  */
 int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const float *x_res, const void *w_res_split,

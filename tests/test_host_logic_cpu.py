@@ -266,30 +266,23 @@ def test_no_kernel_spills():
 
 def test_split_weight_packing_reconstructs_the_fp32_weights():
     """fold.pack_conv_weight_split (operand image of csk_tcn_stage_bf16x3): the three bf16 pieces of every element sum back
-    to the fp32 weight the exact path packs (24 significand bits), taps are grouped by residue class modulo the stride
-    ("kinds", 3 tap slots per weight stage, zero slots behind the last tap), padding channels / rows are zero."""
+    to the fp32 weight the exact path packs (24 significand bits), the nine taps sit in class-major order (residue classes
+    modulo the stride), padding channels / rows / slots are zero."""
     from continual_skeletons_amd import fold
     g = torch.Generator().manual_seed(3)
     w = torch.randn(70, 20, 9, 1, generator=g)
     sc = torch.rand(70, generator=g).double() + 0.5
     w32 = (w.double()[:, :, :, 0] * sc[:, None, None]).float()
-    for stride in (1, 2, 3):
+    for stride, order in ((1, list(range(9))), (2, [0, 2, 4, 6, 8, 1, 3, 5, 7]), (3, [0, 3, 6, 1, 4, 7, 2, 5, 8])):
         img = fold.pack_conv_weight_split(w, sc, stride)
-        assert img.dtype == torch.int16
-        pos = 0
-        for rho in range(stride):
-            taps = list(range(rho, 9, stride))
-            slots = -(-len(taps) // 3) * 3
-            n = 2 * slots * 3 * 2 * 128 * 8                                # [c16 = 2][slots][3][2][Mpad = 128][8]
-            kind = img[pos:pos + n].view(torch.bfloat16).float().view(2, slots, 3, 2, 128, 8)
-            pos += n
-            rec = kind.sum(2).permute(3, 0, 2, 4, 1).reshape(128, 32, slots)   # [co][c][slot]
-            assert torch.equal(rec[:70, :20, : len(taps)], w32[:, :, taps])     # exact: h + m + l == the fp32 value
-            assert float(rec[70:].abs().max()) == 0 and float(rec[:, 20:].abs().max()) == 0
-            assert float(rec[:, :, len(taps):].abs().max() if slots > len(taps) else 0.0) == 0
-        assert pos == img.numel()
+        assert img.dtype == torch.int16 and img.numel() == 2 * 9 * 3 * 2 * 128 * 8        # [c16 = 2][9][3][2][Mpad = 128][8]
+        kind = img.view(torch.bfloat16).float().view(2, 9, 3, 2, 128, 8)
+        rec = kind.sum(2).permute(3, 0, 2, 4, 1).reshape(128, 32, 9)                      # [co][c][slot]
+        assert torch.equal(rec[:70, :20], w32[:, :, order])                               # exact: h + m + l == the fp32 value
+        assert float(rec[70:].abs().max()) == 0 and float(rec[:, 20:].abs().max()) == 0
     one = fold.pack_conv_weight_split(torch.randn(8, 5, 1, 1, generator=g), torch.ones(8, dtype=torch.float64), 2)
-    assert one.numel() == 1 * 3 * 3 * 2 * 64 * 8                               # k = 1: one kind, one stage, one tap
+    assert one.numel() == 1 * 3 * 3 * 2 * 64 * 8                                          # k = 1: tap 0 + two zero slots
+    assert float(one.view(torch.bfloat16).float().view(1, 3, 3, 2, 64, 8)[:, 1:].abs().max()) == 0
     with pytest.raises(ValueError):
         fold.pack_conv_weight_split(torch.randn(8, 5, 3, 1), torch.ones(8, dtype=torch.float64))
 
