@@ -210,7 +210,7 @@ def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, paral
         lt.enabled = False
         tcn_ms, n_launch = lt.total_ms(), len(lt.records)
     assert out is not None and out.shape == (streams * world, NTU["classes"]) and bool(torch.isfinite(out).all())
-    return dt, tcn_ms, n_launch, eng.state_bytes()
+    return dt, tcn_ms, n_launch, (eng.state_bytes(), eng.scratch_bytes())
 
 
 def cpu_baseline_step(seed, threads, budget_s=20.0, adaptive=False):
@@ -313,6 +313,7 @@ def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2, cpu_thread
     step_dt = (time.perf_counter() - t0) / 12
     assert out is not None and out.shape == (streams, 400) and bool(torch.isfinite(out).all())
     sbytes = eng.state_bytes()
+    scratch = eng.scratch_bytes()
     del eng
     gc.collect()
     torch.cuda.empty_cache()
@@ -323,7 +324,7 @@ def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2, cpu_thread
                           "roofline_config": workmodel.roofline_config(cfa, cby, clip_dt, cfe), "cpu_baseline": cpu_clip},
             "coagcn_online": {"value": round(4 * streams / step_dt, 1), "unit": "frames/s", "streams": streams,
                               "stream_shards": shards, "frames_per_launch": 4, "ms_per_frame_step": round(step_dt / 4 * 1e3, 4),
-                              "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
+                              "state_slab_GB_per_gpu": round(sbytes / 1e9, 3), "split_k_scratch_GB_per_gpu": round(scratch / 1e9, 3),
                               "roofline_config": workmodel.roofline_config(sfa, sby, step_dt, sfe), "cpu_baseline": cpu_step}}
 
 
@@ -567,7 +568,8 @@ def main():
                    "roofline_config_frac": workmodel.roofline_config(tfa * world, tby * world, tdt / args.step_cycles, tfe * world)["frac"]}
         step_info = {"metric": "skeleton frames/sec (CoST-GCN online step, NTU-60 shape)", "value": round(fps, 1),
                      "unit": "frames/s", "streams_per_gpu": args.streams, "stream_shards": args.stream_shards, "frames_per_launch": args.frames_per_launch, "ms_per_frame_step": round(sdt / args.step_cycles / args.frames_per_launch * 1e3, 4),
-                     "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes / 1e9, 3),
+                     "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes[0] / 1e9, 3),
+                     "split_k_scratch_GB_per_gpu": round(sbytes[1] / 1e9, 3),
                      "roofline": {"bound": "mfma", "kernel": "tcn_step_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,
                                   "avg_launch_ms": round(stcn_ms / max(1, sn), 4),
