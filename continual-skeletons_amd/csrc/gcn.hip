@@ -832,7 +832,9 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     // activation staging sweeps per row: whole frames of the tile only (no temporal halo), i.e. < NT + 2 V positions:
     // <= 256 for 128-wide and <= 384 for 256-wide tiles at V <= 64 -- 3-4 / 5-6 sweeps of 64 lanes (all spill-free)
     // dense per-segment adjacency (A-GCN clip form): aggregation on the matrix pipe, frame-aligned tiles
-    if (p.dense && !p.adj_per_frame && V >= 4 && V <= 32 && NT / V >= 1 && frames * (int64_t)V >= 4 && !csk_diag_flag("CSK_GCN_VALU_AGG")) {
+    // (128-row tiles only: on the 64-row tiles of the C_out = 64 layers the VALU aggregation of the general kernel measured
+    // 0.31 ms per launch against 0.34 ms for this form -- profiles/r03a_agcn_clip_layers.md vs r03b)
+    if (big && p.dense && !p.adj_per_frame && V >= 4 && V <= 32 && NT / V >= 1 && frames * (int64_t)V >= 4 && !csk_diag_flag("CSK_GCN_VALU_AGG")) {
         const int KC2 = 8;
         p.lds_frames = NT / V;                                  // FT: whole frames per tile
         int ldbx = round_up(p.lds_frames * V, 4);
@@ -841,8 +843,7 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
         p.qtiles = (frames + p.lds_frames - 1) / p.lds_frames;
         if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
         const size_t ldsd = (size_t)(p.R * KC2 * MT + 3 * KC2 * NT + KC2 * ldbx + 3 * V * V) * sizeof(float);
-        void (*kd)(GcnParams) = !big ? (p.R == 4 ? gcn_stage_dense_kernel<64, true, 8, 3> : gcn_stage_dense_kernel<64, false, 8, 3>)
-                                     : (p.R == 4 ? gcn_stage_dense_kernel<128, true, 8, 3> : gcn_stage_dense_kernel<128, false, 8, 3>);
+        void (*kd)(GcnParams) = p.R == 4 ? gcn_stage_dense_kernel<128, true, 8, 3> : gcn_stage_dense_kernel<128, false, 8, 3>;
         if (const int e = csk_ensure_lds((const void *)kd, ldsd)) return e;
         hipLaunchKernelGGL(kd, dim3(p.qtiles * p.mtiles * n_seg), dim3(NTHREADS), ldsd, (hipStream_t)stream, p);
         return (int)hipGetLastError();

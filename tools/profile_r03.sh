@@ -31,5 +31,7 @@ for prec in f32 bf16x3; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write_$prec" -- python3 "$R/tools/clip_pass.py" --precision $prec --forwards 2 > "$out/write_$prec.log" 2>&1
 done
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$out/sq_agcn" -- python3 "$R/tools/agcn_prof.py" 64 3 > "$out/sq_agcn.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch_agcn" -- python3 "$R/tools/agcn_prof.py" 64 3 > "$out/fetch_agcn.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write_agcn" -- python3 "$R/tools/agcn_prof.py" 64 3 > "$out/write_agcn.log" 2>&1
 find "$out" -name "*agent_info.csv" -delete
 du -sh "$out"
