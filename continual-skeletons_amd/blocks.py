@@ -82,7 +82,8 @@ def set_precision(module: nn.Module, precision: str = "f32") -> nn.Module:
     the bf16 matrix pipe, fp32 accumulation (csrc/tcn_split.hip).  Results differ from "f32" by a few 1e-6 on O(1)
     activations (tests/test_gpu_precision_modes.py records the measured error); it is never reported as fp32.  Applies
     to the 9 x 1 temporal conv + 1 x 1 residual conv of SpatioTemporalBlock / CoSpatioTemporalBlock (70 % of the FLOPs);
-    the graph conv stays exact fp32."""
+    and to the channel-mixing GEMM of plain ``GraphConvolution`` modules with 128-row tiles (the adjacency aggregation stays
+    exact fp32; the 64-channel layers and A-GCN's adaptive graph conv keep the exact kernels)."""
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
     hit = 0
@@ -93,6 +94,9 @@ def set_precision(module: nn.Module, precision: str = "f32") -> nn.Module:
             m.precision = precision
             m.refold()
             hit += 1
+        elif type(m) is GraphConvolution:
+            m.precision = precision
+            m.refold()
     if not hit:
         raise ValueError("no SpatioTemporalBlock below this module: nothing to set")
     for m in module.modules():
@@ -134,8 +138,17 @@ class GraphConvolution(_Folded):
         init_weights(self.bn, bs=1e-6)
         self.relu = nn.ReLU()
 
+    precision = "f32"      # or "bf16x3" (opt-in, set_precision): arithmetic of the channel-mixing GEMM of the clip forward
+
     def _fold(self):
-        return fold.fold_graph_conv(self.state_dict())
+        return fold.fold_graph_conv(self.state_dict(), split=self.precision == "bf16x3")
+
+    def _split_applies(self, ops):
+        """csk_gcn_stage_bf16x3 is built for skeleton-sparse graphs and 128-row tiles; other shapes (the 64-channel
+        layers) keep the exact kernel in that mode."""
+        cnt = ops["ell_cnt_host"]
+        return (self.precision == "bf16x3" and ops["w_split"] is not None and self.out_channels % 128 == 0
+                and int(cnt[0]) <= 1 and int(cnt[1]) <= 1 and int(cnt[2]) <= 4)
 
     def forward(self, x):
         self._require_eval()
@@ -145,6 +158,13 @@ class GraphConvolution(_Folded):
         if v != ops["V"]:
             raise RuntimeError(f"input has V={v} joints, adjacency has {ops['V']}")
         y = torch.empty((n, self.out_channels, t, v), device=x.device, dtype=torch.float32)
+        if self._split_applies(ops):
+            rc = native.lib().csk_gcn_stage_bf16x3(
+                native.ptr(x), native.ptr(y), native.ptr(ops["w_split"]), native.ptr(ops["w_res_split"]), native.ptr(ops["bias"]),
+                native.ptr(ops["ell_src"]), native.ptr(ops["ell_val"]), native.ptr(ops["ell_cnt_host"]), ops["ell_w"], n, c,
+                self.out_channels, t, v, ops["res_mode"], native.stream_of(x))
+            native.check(rc, "csk_gcn_stage_bf16x3")
+            return y
         gcn_stage(x, y, ops, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v))
         return y
 

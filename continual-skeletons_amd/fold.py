@@ -54,10 +54,13 @@ def pack_conv_weight_split(weight: torch.Tensor, scale: torch.Tensor, stride: in
     tap order -- taps 0, s, 2s, ... then 1, 1 + s, ... for stride s (the taps of a residue class read one de-interleaved
     set of source frames; for s = 1 the natural order).  K = 1 (the residual conv): three slots, tap 0 and two zero slots.
     The pieces are taken from the SAME fp32 value the exact-fp32 path packs (fp64 fold, one rounding to fp32)."""
-    co, ci, k, _ = weight.shape
-    if k not in (1, 9):
-        raise ValueError(f"split weights are built for the 9 x 1 temporal conv and the 1 x 1 residual conv, got k = {k}")
-    w32 = (weight.double()[:, :, :, 0] * scale[:, None, None]).float()            # (co, ci, k), as pack_conv_weight
+    if weight.dim() == 4:
+        weight = weight[:, :, :, 0]
+    co, ci, k = weight.shape
+    if k not in (1, 3, 9):
+        raise ValueError(f"split weights are built for the 9 x 1 temporal conv, the 1 x 1 residual convs and the 3 graph-conv "
+                         f"subsets, got k = {k}")
+    w32 = (weight.double() * scale[:, None, None]).float()                         # (co, ci, k), as pack_conv_weight
     cpad, mpad = _ceil_to(ci, SPLIT_KS), _ceil_to(co, MT)
     taps = [r for rho in range(min(stride, k)) for r in range(rho, k, stride)] if k > 1 else [0]
     slots = _ceil_to(len(taps), 3)
@@ -94,9 +97,10 @@ def ell_from_dense(a_eff: torch.Tensor):
     return torch.from_numpy(src), torch.from_numpy(val), torch.from_numpy(cnt), ew
 
 
-def fold_graph_conv(sd: Dict[str, torch.Tensor], p: str = "") -> dict:
+def fold_graph_conv(sd: Dict[str, torch.Tensor], p: str = "", split: bool = False) -> dict:
     """Packed operands of csk_gcn_stage_f32 from a GraphConvolution state_dict (keys of
-    models/base.py:231-258)."""
+    models/base.py:231-258).  split: also the bf16x3 operand images of csk_gcn_stage_bf16x3 (the three subsets in the
+    role of three taps; the conv gcn_residual as a one-tap image)."""
     sd = {k: v.detach().cpu() for k, v in sd.items() if k.startswith(p)}
     s, t = bn_affine(sd[p + "bn.weight"], sd[p + "bn.bias"], sd[p + "bn.running_mean"], sd[p + "bn.running_var"])
     co, ci = sd[p + "g_conv.0.weight"].shape[:2]
@@ -114,8 +118,15 @@ def fold_graph_conv(sd: Dict[str, torch.Tensor], p: str = "") -> dict:
         bias += sr * sd[p + "gcn_residual.0.bias"].double() + tr
     a_eff = sd[p + "A"].double() * sd[p + "graph_attn"].double()       # models/base.py:262
     src, val, cnt, ew = ell_from_dense(a_eff)
-    return dict(w=w.float().contiguous(), bias=pad_vec(bias), ell_src=src, ell_val=val, ell_cnt_host=cnt,
-                ell_w=ew, c_in=ci, c_out=co, res_mode=2 if conv_res else 1, V=a_eff.shape[-1])
+    out = dict(w=w.float().contiguous(), bias=pad_vec(bias), ell_src=src, ell_val=val, ell_cnt_host=cnt,
+               ell_w=ew, c_in=ci, c_out=co, res_mode=2 if conv_res else 1, V=a_eff.shape[-1], w_split=None, w_res_split=None)
+    if split:
+        one = torch.ones(co, dtype=torch.float64)                      # the BN scale is already folded into w
+        w3 = w[:3, :ci, :co].permute(2, 1, 0).contiguous()             # (co, ci, 3 subsets), fp64
+        out["w_split"] = pack_conv_weight_split(w3, one)
+        if conv_res:
+            out["w_res_split"] = pack_conv_weight_split(w[3, :ci, :co].t().contiguous().unsqueeze(-1), one)
+    return out
 
 
 def fold_temporal_conv(sd: Dict[str, torch.Tensor], p: str = "") -> dict:

@@ -21,6 +21,7 @@ SIGNATURES = {
     "csk_tcn_stage_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "csk_conv1x1_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _p],
     "csk_tcn_stage_bf16x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "csk_gcn_stage_bf16x3": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "csk_input_norm_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _p],
     "csk_pool_fc_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "csk_fc_f32": [_p, _p, _p, _p, _i, _i, _i, _p],

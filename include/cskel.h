@@ -131,6 +131,19 @@ int csk_tcn_stage_bf16x3(const float *y, const void *w_split, const float *x_res
                          int res_mode, int c_res, int t_res, int res_off, int relu, void *stream);
 
 /*
+ * OPT-IN precision mode "bf16x3" of csk_gcn_stage_f32 (same reference method, models/base.py:260-270) for skeleton-sparse
+ * graphs (<= 1/1/4 non-zeros per adjacency column), C_out a multiple of 128 and contiguous (n_seg, C, frames, V) tensors:
+ * the adjacency aggregation stays exact fp32, the channel-mixing GEMM runs on the bf16 matrix pipe with its operands split
+ * into three bf16 pieces (fp32-grade, see csk_tcn_stage_bf16x3).
+ *  w_split      split image of the three 1 x 1 convs (BN scale folded): [c_in_pad / 16][3 subsets][3 pieces][2 halves][c_out_pad]
+ *  w_res_split  split image of the conv gcn_residual, [c_in_pad / 16][3 slots: the conv, zero, zero][3][2][c_out_pad], or NULL
+ *  bias, ell_*  as csk_gcn_stage_f32 (shared adjacency: adj_seg_stride = 0)
+ */
+int csk_gcn_stage_bf16x3(const float *x, float *y, const void *w_split, const void *w_res_split, const float *bias,
+                         const int32_t *ell_src, const float *ell_val, const int32_t *ell_cnt, int ell_w,
+                         int n_seg, int c_in, int c_out, int frames, int V, int res_mode, void *stream);
+
+/*
  * Input permute + data_bn + reshape, models/st_gcn/st_gcn.py:49-57 (clip) and
  * models/base.py:73-82 (per frame, t = 1):
  *     h[n*M+m, c, t, v] = x[n, c, t, v, m] * scale[(m*V+v)*C+c] + shift[(m*V+v)*C+c]

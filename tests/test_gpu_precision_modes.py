@@ -133,6 +133,41 @@ def test_config2_batch256_clip_forward_bf16x3():
     assert torch.equal(part, full[64:128])
 
 
+@pytest.mark.parametrize("ci,co,T,N,v", [(64, 128, 33, 2, 25), (128, 128, 40, 3, 25), (128, 256, 21, 2, 25), (256, 256, 17, 2, 18),
+                                         (70, 128, 9, 1, 25), (256, 256, 1, 5, 25)])
+def test_graph_conv_vs_oracle_bf16x3(ci, co, T, N, v):
+    """csk_gcn_stage_bf16x3 (channel mix of the graph conv in split arithmetic, 128-row tiles): identity and conv
+    gcn_residual, ragged tiles, odd channel counts, vs the oracle and vs the exact kernel."""
+    from tests.helpers import GCN_OUT_KEYS
+    g = torch.Generator().manual_seed(77 + ci + co + T)
+    m = pkg.GraphConvolution(ci, co, _A(v)).eval()
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("graph_attn") or ("bn" in name and name.endswith("weight")) or name.endswith("residual.1.weight"):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand(prm.shape, generator=g) - 0.5)
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
+    sd = {k: t.clone() for k, t in m.state_dict().items()}
+    x = torch.rand(N, ci, T, v, generator=g)
+    want = unit_scale_(m, sd, lambda s: o.graph_conv(x, s), GCN_OUT_KEYS)
+    m = m.to(DEV)
+    exact = m(x.to(DEV)).cpu()
+    m.precision = MODE
+    m.refold()
+    assert m._split_applies(m._packed_ops(torch.device(DEV)))
+    got = m(x.to(DEV)).cpu()
+    check_parity(got, want, mode=MODE, shape=(ci, co, T, N, v))
+    check_parity(got, exact, mode=MODE, note="vs the exact-fp32 kernel")
+    m.precision = "f32"
+    m.refold()
+    assert torch.equal(m(x.to(DEV)).cpu(), exact)
+
+
 def test_continual_stepping_refuses_bf16x3_but_clip_forward_works():
     """The split kernels exist for the clip form only: a continual block in bf16x3 mode computes ``forward`` (clip) with
     them and refuses to step (no silent fall-back to another arithmetic)."""

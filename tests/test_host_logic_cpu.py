@@ -283,8 +283,10 @@ def test_split_weight_packing_reconstructs_the_fp32_weights():
     one = fold.pack_conv_weight_split(torch.randn(8, 5, 1, 1, generator=g), torch.ones(8, dtype=torch.float64), 2)
     assert one.numel() == 1 * 3 * 3 * 2 * 64 * 8                                          # k = 1: tap 0 + two zero slots
     assert float(one.view(torch.bfloat16).float().view(1, 3, 3, 2, 64, 8)[:, 1:].abs().max()) == 0
+    three = fold.pack_conv_weight_split(torch.randn(8, 5, 3, generator=g), torch.ones(8, dtype=torch.float64))   # graph-conv subsets
+    assert three.numel() == 1 * 3 * 3 * 2 * 64 * 8
     with pytest.raises(ValueError):
-        fold.pack_conv_weight_split(torch.randn(8, 5, 3, 1), torch.ones(8, dtype=torch.float64))
+        fold.pack_conv_weight_split(torch.randn(8, 5, 5, 1), torch.ones(8, dtype=torch.float64))
 
 
 def test_new_entry_points_validate_their_arguments_without_a_gpu():
