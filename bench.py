@@ -513,7 +513,7 @@ def main():
             line["clip_bf16x3"] = {
                 "metric": "clips/sec (ST-GCN clip forward, temporal conv in the opt-in bf16x3 split arithmetic)",
                 "value": round(B * world * args.steps / dt3, 2), "unit": "clips/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-                "dtype": "bf16x3-split, f32 accumulate (temporal conv); f32 (graph conv, head)",
+                "dtype": "bf16x3-split, f32 accumulate (temporal conv; channel mix of the graph conv on 128-row layers); f32 (adjacency aggregation, 64-channel graph convs, head)",
                 "speedup_vs_f32": round(dt / dt3, 3),
                 "max_abs_logit_diff_vs_f32": inf3.get("max_abs_diff_vs_f32"), "logit_absmax": inf3.get("logit_absmax"),
                 "tcn_stage": {"avg_launch_ms": round(tcn3_ms / max(1, n3), 4), "launches_timed": n3,
@@ -522,7 +522,7 @@ def main():
                               "frac_of_bf16_peak": round(6 * tcn_fl / 10.0 / (tcn3_ms / 1e3 / max(1, n3)) / 1e12 / 2500.0, 4),
                               "note": "6 bf16 MFMA products per fp32 product: executed FLOPs = 6 x the fp32-equivalent; peak 2.5 PFLOP/s dense bf16"},
                 "fp32_path_tcn_stage_avg_launch_ms": round(avg_launch_s * 1e3, 4),
-                "scope": "clip kernels only (csk_tcn_stage_bf16x3); the continual step kernels stay exact fp32 (DESIGN.md)"}
+                "scope": "clip kernels only (csk_tcn_stage_bf16x3, csk_gcn_stage_bf16x3); the continual step kernels stay exact fp32 (DESIGN.md)"}
         if use_dist:
             # BASELINE.json configs[4]: batch 8192 over 8 GPUs = 1024 clips per GPU + the RCCL logit all-gather.  Reported
             # beside the 256 / GPU weak-scaling headline (which stays comparable with the N = 1 line); at N = 8 this IS

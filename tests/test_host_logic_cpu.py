@@ -321,3 +321,18 @@ def test_set_precision_marks_blocks_and_refolds():
     assert m.layers["layer5"]._fold()["w_split"] is None
     with pytest.raises(ValueError):
         pkg.set_precision(m, "fp16")
+
+
+def test_gcn_bf16x3_entry_validates_arguments_without_a_gpu():
+    import ctypes as C
+    lib = pkg.native.lib()
+    fake = C.c_void_p(0x1000)
+    cnt = (C.c_int32 * 3)(1, 1, 4)
+
+    def call(c_out=128, cnt_=cnt, res=1, c_in=128, wres=None):
+        return lib.csk_gcn_stage_bf16x3(fake, fake, fake, wres, fake, fake, fake, C.cast(cnt_, C.c_void_p), 4, 2, c_in, c_out, 10, 25,
+                                        res, None)
+    assert call(c_out=64) == -1 and b"multiple of 128" in lib.csk_last_error()
+    assert call(cnt_=(C.c_int32 * 3)(2, 1, 4)) == -1 and b"skeleton-sparse" in lib.csk_last_error()
+    assert call(c_in=64) == -1 and b"identity residual" in lib.csk_last_error()
+    assert call(c_in=64, res=2) == -1 and b"conv residual without" in lib.csk_last_error()
