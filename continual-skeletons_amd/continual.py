@@ -666,6 +666,9 @@ class CoStGcn(_Folded):
             raise RuntimeError(f"frame shape {tuple(x0.shape)} does not match input_shape {self.input_shape}")
         if self._n != n or self._xin0.device != x0.device:           # clean_state_on_shape_change (base.py:161-164)
             self._bind(n, x0.device)
+        if any(self.layers[f"layer{i + 1}"].precision != "f32" for i in range(10)):
+            raise NotImplementedError("precision 'bf16x3' covers the clip kernels only (DESIGN.md section 4): step with the default "
+                                      "precision -- set_precision(model, 'f32')")
         if self._flushed:
             raise RuntimeError("the state was flushed by forward_steps(pad_end=True): the end padding has consumed ring slots "
                                "and advanced the blocks past the input frame count; call clean_state() before stepping on")

@@ -185,6 +185,22 @@ def test_continual_stepping_refuses_bf16x3_but_clip_forward_works():
     assert blk.forward_step(x[:, :, 0].contiguous()) is None       # back to the default: stepping works (no output yet)
 
 
+def test_costgcn_model_refuses_to_step_in_bf16x3_with_either_engine():
+    a, sd, x = g6_state_dict("ntu")
+    for native_plan in (True, False):
+        co = pkg.CoStGcn(_A(), pool_size=4, pool_padding=1).eval()
+        co.use_native_plan = native_plan
+        co.load_state_dict(sd, strict=True)
+        co = co.to(DEV)
+        f = x[:1, :, 0].contiguous().to(DEV)
+        assert co.forward_step(f) is None                        # default precision: steps
+        pkg.set_precision(co, MODE)
+        with pytest.raises(NotImplementedError, match="clip kernels only"):
+            co.forward_step(f)
+        check_parity(co.forward(x[:1].to(DEV)).cpu(), pkg.set_precision(co, "f32").forward(x[:1].to(DEV)).cpu(), mode=MODE,
+                     note="CoStGcn.forward (clip form) in bf16x3 vs f32")
+
+
 def test_precision_argument_errors():
     m = pkg.SpatioTemporalBlock(4, 4, _A()).eval()
     with pytest.raises(ValueError, match="precision must be"):
