@@ -21,7 +21,7 @@ def rows_of(pattern):
 
 
 def short(name):
-    for k in ("tcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
+    for k in ("tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
               "agcn_logits_partial_kernel", "agcn_softmax_kernel", "input_norm_kernel", "pool_kernel", "fc_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
@@ -67,7 +67,7 @@ def main(tag, out_tag):
         for k in sorted(sq, key=lambda kk: -sum(dur[kk])):
             c = sq[k]
             g = sum(c.get("GRBM_GUI_ACTIVE", [0])) / 8
-            if g == 0 or "stage" not in k and "agcn" not in k:
+            if g == 0 or ("stage" not in k and "agcn" not in k):
                 continue
             wc = sum(c["SQ_WAVE_CYCLES"])
             secs = sum(dur[k]) / 1e3
