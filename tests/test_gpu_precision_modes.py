@@ -201,6 +201,29 @@ def test_costgcn_model_refuses_to_step_in_bf16x3_with_either_engine():
                      note="CoStGcn.forward (clip form) in bf16x3 vs f32")
 
 
+def test_split_kernels_are_deterministic_across_launches():
+    """Race screen of the new pipelines (ping-pong weight stages, single-buffered activation tile, aggregate-then-MFMA of
+    the graph-conv split kernel, partial-logit attention): the same inputs must give the same bits on every launch, at a
+    size where every CU runs several tiles back to back."""
+    a, sd, x = g6_state_dict("ntu")
+    net = pkg.StGcn(_A()).eval()
+    net.load_state_dict(sd, strict=True)
+    pkg.set_precision(net, MODE)
+    net = net.to(DEV)
+    xb = torch.rand((48, 3, 300, 25, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    ref = net(xb)
+    for _ in range(12):
+        assert torch.equal(net(xb), ref)
+    ag = pkg.AGcn(_A(18), (3, 300, 18, 2), 400).eval()
+    a8, sd8, x8 = g8_state_dict()
+    ag.load_state_dict(sd8, strict=True)
+    ag = ag.to(DEV)
+    xk = torch.rand((24, 3, 300, 18, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(10))
+    ref = ag(xk)
+    for _ in range(8):
+        assert torch.equal(ag(xk), ref)
+
+
 def test_precision_argument_errors():
     m = pkg.SpatioTemporalBlock(4, 4, _A()).eval()
     with pytest.raises(ValueError, match="precision must be"):
