@@ -108,17 +108,28 @@ __global__ __launch_bounds__(NTH2, 2) void tcn_split_stage_kernel(const TcnSplit
         if (nst > 1) ws.issue(wb + sstride, p.Mpad, tid);
         if (nchunks > 1) bs.issue(seg_base, p.C, cs, KS);
         __syncthreads();
+        const bool early = wave < 4 || (p.diag & 16);
         for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
             for (int s = 0; s < NSTAGE; ++s) {
                 const int g = c * NSTAGE + s;
                 u32x4 *cur = Wl0 + (g & 1) * WSZ, *oth = Wl0 + ((g & 1) ^ 1) * WSZ;
-                if (g + 1 < nst && !(p.diag & 1)) ws.commit(oth, tid);
-                if (g + 2 < nst && !(p.diag & 1)) ws.issue(wb + (g + 2) * sstride, p.Mpad, tid);
+                // Stagger: the two waves of a SIMD (w and w + 4) run the stage's vector / memory work and its MFMAs in
+                // opposite orders, so one feeds the matrix pipe while the other stages -- both orders are legal inside the
+                // barrier interval (the staging writes the OTHER weight buffer and registers only)
+                auto stage_work = [&]() {
+                    if (g + 1 < nst && !(p.diag & 1)) ws.commit(oth, tid);
+                    if (g + 2 < nst && !(p.diag & 1)) ws.issue(wb + (g + 2) * sstride, p.Mpad, tid);
+                };
+                auto stage_mfma = [&]() {
+                    __builtin_amdgcn_s_setprio(1);
+                    if (!(p.diag & 4)) mfma_split_taps<MT, TG>(cur, Bl, p.ldb, toff + s * TG, offA, off[0], off[1], kh, acc);
+                    __builtin_amdgcn_s_setprio(0);
+                };
+                if (early) stage_work();
                 if (PRE && s == NSTAGE - 1 && c + 1 < nchunks) bs.presplit();      // next tile's pieces, beside this stage's MFMAs
-                __builtin_amdgcn_s_setprio(1);
-                if (!(p.diag & 4)) mfma_split_taps<MT, TG>(cur, Bl, p.ldb, toff + s * TG, offA, off[0], off[1], kh, acc);
-                __builtin_amdgcn_s_setprio(0);
+                stage_mfma();
+                if (!early) stage_work();
                 if (!(p.diag & 8)) __syncthreads();
             }
             if (c + 1 < nchunks && !(p.diag & 2)) {
