@@ -6,27 +6,11 @@
 #include <type_traits>
 
 #include "mfma_core.h"
+#include "gcn_params.h"
 
 // ------------------------------------------------------------------------------------------------
 // GCN stage
 // ------------------------------------------------------------------------------------------------
-struct GcnParams {
-    const float *x, *w, *bias;
-    float *y;
-    const int32_t *ell_src;
-    const float *ell_val;
-    int ell_cnt[3];
-    int ell_w;
-    int64_t adj_seg_stride, x_seg_stride, x_chan_stride, y_seg_stride, y_chan_stride;
-    int Cin, CinPad, Cout, Mpad, frames, V, R, res_mode, ldb;
-    unsigned vmagic, mtiles, qtiles;
-    int dense;   // src[e] == e for all subsets and columns (checked on the host side of the ABI by construction)
-    int adj_per_frame;   // the (dense) adjacency varies per FRAME of a segment: index = seg * frames + frame
-    int lds_frames;      // frames of adjacency staged per workgroup in that mode
-    int fast_epi;        // channel strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
-    int no_pair_reads;   // diagnostic (CSK_NO_PAIR_READS): general kernel aggregates with scalar LDS reads for even V too
-    int no_vec;          // diagnostic (CSK_GCN_NOVEC): sparse kernel stages activations element-wise on every tile
-};
 
 template <int MT, int NJ>
 __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams p) {
@@ -828,6 +812,12 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
         if (e) return e;
         hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds2, (hipStream_t)stream, p);
         return (int)hipGetLastError();
+    }
+    // dense per-sample / per-frame adjacency with an even V <= 18: on-the-fly aggregation from register-resident adjacency
+    // columns (gcn_dense.hip); every other dense shape continues below
+    if (p.dense && !csk_diag_flag("CSK_GCN_DENSE_OLD")) {
+        const int rc = csk_launch_gcn_dense2(p, n_seg, stream);
+        if (rc != -2) return rc;
     }
     // activation staging sweeps per row: whole frames of the tile only (no temporal halo), i.e. < NT + 2 V positions:
     // <= 256 for 128-wide and <= 384 for 256-wide tiles at V <= 64 -- 3-4 / 5-6 sweeps of 64 lanes (all spill-free)

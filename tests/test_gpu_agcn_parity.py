@@ -42,7 +42,10 @@ def _randomise(m, seed):
                 buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
 
 
-@pytest.mark.parametrize("ci,co,t,v", [(64, 64, 40, 18), (64, 128, 17, 18), (3, 64, 300, 18), (16, 16, 9, 25)])
+# V = 18: gcn_stage_dense2_kernel (on-the-fly dense aggregation; 64- and 128-row tiles, identity and conv residual, a last tile
+# of 1 ... 6 frames, C_out below the tile height); V = 25: the kernels of gcn.hip
+@pytest.mark.parametrize("ci,co,t,v", [(64, 64, 40, 18), (64, 128, 17, 18), (3, 64, 300, 18), (16, 16, 9, 25), (128, 128, 10, 18),
+                                       (256, 256, 15, 18), (16, 24, 9, 18), (128, 256, 1, 18), (40, 40, 7, 18)])
 def test_adaptive_graph_conv_vs_oracle(ci, co, t, v):
     A = A_KIN if v == 18 else pkg.ntu_graph().A
     m = pkg.AdaptiveGraphConvolution(ci, co, A).eval()
