@@ -43,6 +43,10 @@ class AdaptiveGraphConvolution(GraphConvolution):
         be = torch.cat([sd[f"a_conv.{i}.bias"] for i in range(3)] + [sd[f"b_conv.{i}.bias"] for i in range(3)], 0)
         f["w_embed"] = fold.pack_conv_weight(we.view(6 * inter, ci, 1, 1), torch.ones(6 * inter, dtype=torch.float64))
         f["b_embed"] = fold.pad_vec(be.double())
+        # pair-major row order (a_i rows, then b_i rows, i = 0, 1, 2) for the fused step kernel
+        order = [r for i in range(3) for r in list(range(i * inter, (i + 1) * inter)) + list(range((3 + i) * inter, (4 + i) * inter))]
+        f["w_embed_pairs"] = fold.pack_conv_weight(we[order].view(6 * inter, ci, 1, 1), torch.ones(6 * inter, dtype=torch.float64))
+        f["b_embed_pairs"] = fold.pad_vec(be[order].double())
         return f
 
     def _attention(self, E, ops, n_seg, T, V, e_seg_stride, e_chan_stride, seg_per_group=None, e_group_stride=0):
@@ -80,6 +84,16 @@ class AdaptiveGraphConvolution(GraphConvolution):
         ops = self._packed_ops(x.device)
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
+        if v == 18 and self.inter_c in (16, 32, 64) and x.data_ptr() % 8 == 0 and x_strides[0] % 2 == 0 and p % 2 == 0:
+            # embedding convs + attention in one launch (csk_agcn_embed_attention_step_f32), then the graph conv
+            adj = torch.empty((n_seg * frames, 3, v, v), device=x.device, dtype=torch.float32)
+            rc = native.lib().csk_agcn_embed_attention_step_f32(
+                native.ptr(x), native.ptr(ops["w_embed_pairs"]), native.ptr(ops["b_embed_pairs"]), native.ptr(ops["a_sum"]),
+                native.ptr(adj), n_seg, self.in_channels, self.inter_c, frames, v, x_strides[0], p, native.stream_of(x))
+            native.check(rc, "csk_agcn_embed_attention_step_f32")
+            blocks.gcn_stage(x, y, dict(ops, ell_val=adj), n_seg=n_seg, frames=frames, x_strides=x_strides, y_strides=y_strides,
+                             adj_seg_stride=3 * v * v, adj_per_frame=1)
+            return
         E = torch.empty((n_seg, e_ch, p), device=x.device, dtype=torch.float32)
         # the fused 1x1 embedding conv on the channel-major slots: segment = ring slot, frames = skeletons
         rc = native.lib().csk_conv1x1_f32(native.ptr(x), native.ptr(E), native.ptr(ops["w_embed"]), native.ptr(ops["b_embed"]), n_seg,

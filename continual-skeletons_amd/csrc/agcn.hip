@@ -200,3 +200,202 @@ extern "C" int csk_agcn_attention_f32(const float *E, const float *a_sum, float 
                        3 * n_seg, inter * T, V);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// CoAGCN step form, fused: embedding 1x1 convs + per-skeleton attention in ONE launch (no E tensor in memory).
+// A workgroup takes FT = 128 / V whole skeletons ("frames" of a channel-major slot) and NP (a_i, b_i) pairs:
+//   (1) E[rows][cols] = W_e . x + b_e for its 2 * INTER * NP embedding rows (pair-major row order: a_i rows, then b_i rows)
+//       as an fp32-MFMA GEMM over C_in -- a wave owns all rows x 32 columns, accumulator block i / MFMA row rho = tile row
+//       NB rho + i (one vector LDS read per A operand), ping-pong LDS, register prefetch, one barrier per 16-channel chunk;
+//   (2) the E tile goes to LDS; per (pair, skeleton) one wave forms logits = Ea^T . Eb (INTER / 2 MFMAs), the softmax over v
+//       in registers and writes adj[skeleton][i][w][v] -- the arithmetic of agcn_attention_step_kernel above, operand for
+//       operand (the E values equal csk_conv1x1_f32's: channels are accumulated in the same order).
+// Even V <= 18 (pairs of joints are the staging unit), INTER in {16, 32, 64}; other shapes take the two-launch route.
+// ------------------------------------------------------------------------------------------------
+struct EmbAttParams {
+    const float *x, *w, *bias, *a_sum;
+    float *ell_val;
+    int64_t x_seg_stride, x_chan_stride;
+    int Cin, CinPad, Mpad, frames;
+    unsigned qtiles, mtiles;
+};
+typedef float f32x2a __attribute__((ext_vector_type(2)));
+
+template <int INTER, int NP, int VP>
+__global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_step_kernel(const EmbAttParams p) {
+    constexpr int V = 2 * VP, VPAD = (V + 3) & ~3, NT = 128, FT = NT / V;
+    constexpr int MT = 2 * INTER * NP, NB = MT / 32;
+    constexpr int KC2 = 16, NS = KC2 / 2, NH = NS / 2;
+    constexpr int LDX = FT * VPAD, M4 = MT / 4;
+    constexpr int WB = (KC2 * M4 + NTHREADS - 1) / NTHREADS, XB = KC2 * 64 / NTHREADS, NL = WB + XB;
+    constexpr int WSZ = KC2 * MT, BUFSZ = WSZ + KC2 * LDX;
+    constexpr int ESLD = NT + 4;                          // E tile row stride
+    static_assert(MT % 32 == 0 && FT * VP <= 64 && INTER % 2 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float smem_ea[];      // max(2 * BUFSZ, MT * ESLD) floats
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int mt = (int)(wid % p.mtiles), qt = (int)((wid / p.mtiles) % p.qtiles);
+    const int seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int m0 = mt * MT;
+    const int ta = qt * FT, q0 = ta * V;
+    const int fcnt = min(FT, p.frames - ta);
+    const int ncol = fcnt * V;
+    const int j = wave * 32 + l31;
+    const bool jv = j < ncol;
+    const int jf = jv ? j / V : 0, jw = jv ? j - jf * V : 0;
+    const int xcol = jf * VPAD + jw;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[i][g] = 0.f;
+
+    const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
+    const float *wbase = p.w + m0;
+    f32x4 wv[WB];
+    unsigned wgo[WB], wlo[WB];
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+        const int e = min(u * NTHREADS + tid, KC2 * M4 - 1);
+        const int row = e / M4, m4 = e % M4;
+        wgo[u] = (unsigned)(row * p.Mpad + m4 * 4);
+        wlo[u] = (unsigned)(e * 4);
+    }
+    f32x2a xv2[XB];
+    unsigned xgo, xlo;
+    const int xrow0 = tid >> 6;
+    {
+        const int pr = min(tid & 63, fcnt * VP - 1);
+        const int f = pr / VP, w2 = pr - f * VP;
+        xgo = (unsigned)(q0 + 2 * pr);
+        xlo = (unsigned)(f * VPAD + 2 * w2);
+    }
+    auto issue_one = [&](int i, int c0) {
+        if (i < WB) {
+            wv[i] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)c0 * p.Mpad + wgo[i]);
+        } else {
+            const int c = min(c0 + xrow0 + 4 * (i - WB), p.Cin - 1);         // clamped: padding channels carry zero weights
+            xv2[i - WB] = *reinterpret_cast<const f32x2a *>(seg_base + (int64_t)c * p.x_chan_stride + xgo);
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(buf + wlo[u]) = wv[u];
+#pragma unroll
+        for (int u = 0; u < XB; ++u) *reinterpret_cast<f32x2a *>(buf + WSZ + (xrow0 + 4 * u) * LDX + xlo) = xv2[u];
+    };
+    const int nchunks = p.CinPad / KC2;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_one(i, 0);
+    commit(smem_ea);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) issue_one(i, KC2);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        float *cur = smem_ea + (c & 1) * BUFSZ, *oth = smem_ea + ((c & 1) ^ 1) * BUFSZ;
+        if (c + 1 < nchunks) commit(oth);
+        const int cnext = min(c + 2, nchunks - 1) * KC2;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < NH) {
+#pragma unroll
+                for (int i = s * NL / NH; i < (s + 1) * NL / NH; ++i) issue_one(i, cnext);
+            }
+            const int kk = 2 * s + kh;
+            const float b = cur[WSZ + kk * LDX + xcol];
+            const float *wr = cur + kk * MT + NB * l31;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], b, acc[i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // E tile (+ bias) -> LDS, row-major [tile row][column]
+    float *Es = smem_ea;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = NB * ((g & 3) + 8 * (g >> 2) + 4 * kh) + i;
+            Es[row * ESLD + j] = acc[i][g] + p.bias[m0 + row];
+        }
+    __syncthreads();
+    // attention units (pair, skeleton) dealt to the waves
+    const float inv = 1.f / (float)INTER;
+    const int cl = min(l31, V - 1);
+    const bool col = l31 < V;
+    for (int u = wave; u < NP * fcnt; u += NTHREADS / 64) {
+        const int pr = u / fcnt, f = u - pr * fcnt;
+        const float *ea = Es + (pr * 2 * INTER + kh) * ESLD + f * V + cl;
+        const float *eb = ea + INTER * ESLD;
+        f32x16 lg;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) lg[g] = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < INTER / 2; ++s) lg = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[2 * s * ESLD], eb[2 * s * ESLD], lg, 0, 0, 0);
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            lg[r] *= inv;
+            if (v < V) m = fmaxf(m, lg[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            lg[r] = v < V ? expf(lg[r] - m) : 0.f;
+            sum += lg[r];
+        }
+        sum += __shfl_xor(sum, 32);
+        if (col) {
+            const int pi = mt * NP + pr;
+            const int64_t n = (int64_t)seg * p.frames + ta + f;
+            float *dst = p.ell_val + ((n * 3 + pi) * V + l31) * V;               // [n][i][w][v]
+            const float *as = p.a_sum + (int64_t)pi * V * V + l31;               // [i][v][w]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (v < V) dst[v] = lg[r] / sum + as[v * V];
+            }
+        }
+    }
+}
+
+template <int INTER, int NP>
+static int launch_embed_attention(EmbAttParams p, int n_seg, hipStream_t stream) {
+    constexpr int VP = 9, V = 18, VPAD = 20, FT = 128 / V, MT = 2 * INTER * NP;
+    p.qtiles = (p.frames + FT - 1) / FT;
+    p.mtiles = 3 / NP;
+    const size_t a = 2 * (size_t)(16 * MT + 16 * FT * VPAD), b = (size_t)MT * (128 + 4);
+    const size_t lds = (a > b ? a : b) * sizeof(float);
+    void (*k)(EmbAttParams) = agcn_embed_attention_step_kernel<INTER, NP, VP>;
+    if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(p.qtiles * p.mtiles * n_seg), dim3(NTHREADS), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_agcn_embed_attention_step_f32(const float *x, const float *w_pairs, const float *b_pairs, const float *a_sum,
+                                                 float *ell_val, int n_seg, int c_in, int inter, int frames, int V,
+                                                 int64_t x_seg_stride, int64_t x_chan_stride, void *stream) {
+    if (!x || !w_pairs || !b_pairs || !a_sum || !ell_val) CSK_FAIL("agcn_embed_attention: null pointer");
+    if (n_seg <= 0 || c_in <= 0 || frames <= 0) CSK_FAIL("agcn_embed_attention: bad dims");
+    if (V != 18 || (inter != 16 && inter != 32 && inter != 64))
+        CSK_FAIL("agcn_embed_attention: built for V = 18 and inter in {16, 32, 64} (use csk_conv1x1_f32 + csk_agcn_attention_f32)");
+    if ((reinterpret_cast<uintptr_t>(x) & 7) || (x_seg_stride & 1) || (x_chan_stride & 1))
+        CSK_FAIL("agcn_embed_attention: activation rows must be 8-byte aligned");
+    if ((int64_t)n_seg * frames >= (1ll << 31) / (3 * V * V)) CSK_FAIL("agcn_embed_attention: too many skeletons for one launch");
+    EmbAttParams p;
+    p.x = x; p.w = w_pairs; p.bias = b_pairs; p.a_sum = a_sum; p.ell_val = ell_val;
+    p.x_seg_stride = x_seg_stride; p.x_chan_stride = x_chan_stride;
+    p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD); p.Mpad = round_up(6 * inter, CSK_MT); p.frames = frames;
+    hipStream_t s = (hipStream_t)stream;
+    if (inter == 16) return launch_embed_attention<16, 3>(p, n_seg, s);
+    if (inter == 32) return launch_embed_attention<32, 1>(p, n_seg, s);
+    return launch_embed_attention<64, 1>(p, n_seg, s);
+}

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 9
+#define CSK_ABI_VERSION 10
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -188,6 +188,16 @@ int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *l
 int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, float *scratch, int n_seg, int inter, int T,
                            int V, int64_t e_seg_stride, int64_t e_chan_stride, int seg_per_group, int64_t e_group_stride,
                            void *stream);
+
+/* CoAGCN step form of the two entries above in ONE launch (models/coa_gcn/coa_gcn.py:11-14: the module applied per frame, T = 1):
+ * the six embedding 1x1 convs and the per-skeleton attention, without the E tensor in memory.  x: n_seg channel-major slots of
+ * `frames` skeletons (element (seg, c, skeleton, v) at seg*x_seg_stride + c*x_chan_stride + skeleton*V + v, rows 8-byte
+ * aligned); w_pairs / b_pairs: the embedding weights packed as for csk_conv1x1_f32 ([C_in_pad][C_out_pad], C_out = 6*inter) but
+ * in PAIR-MAJOR row order: rows i*2*inter + k = a_conv_i[k], i*2*inter + inter + k = b_conv_i[k].  Output: ell_val[(seg*frames +
+ * skeleton)][i][w][v] as csk_agcn_attention_f32 writes it.  Built for V = 18 and inter in {16, 32, 64}; fails otherwise. */
+int csk_agcn_embed_attention_step_f32(const float *x, const float *w_pairs, const float *b_pairs, const float *a_sum,
+                                      float *ell_val, int n_seg, int c_in, int inter, int frames, int V, int64_t x_seg_stride,
+                                      int64_t x_chan_stride, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Continual (frame-by-frame) path.  The arithmetic the reference delegates to the third-party package
