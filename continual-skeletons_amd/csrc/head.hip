@@ -38,19 +38,34 @@ __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ h, 
     if (lane == 0) feat[row] = s / (float)((int64_t)M * TV) * scale;
 }
 
-// logits[n, k] = feat[n] . fc_w[k] + fc_b[k]; one wave per output
+// logits[n, k] = feat[n] . fc_w[k] + fc_b[k].  One THREAD per output, a wave = 64 classes of one sample: the feature row is
+// wave-uniform (scalar loads), every lane streams its own weight row 16 bytes at a time (a 64-byte line serves four
+// iterations), the sum runs in four interleaved chains over c -- no cross-lane reduction.  (First form: one wave per output with a 6-step
+// butterfly each; 98 us per cycle for the 400 Kinetics classes of 4096 skeleton frames, profiles/r03d_coagcn_online_1shard.md.)
 __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ feat, const float *__restrict__ w,
                                                  const float *__restrict__ b, float *__restrict__ logits, int N, int C,
-                                                 int classes) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t o = (int64_t)blockIdx.x * 4 + wave;
-    if (o >= (int64_t)N * classes) return;
-    const int n = o / classes, k = o % classes;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(feat[(int64_t)n * C + c], w[(int64_t)k * C + c], s);
+                                                 int classes, int ktiles) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wid >= (int64_t)N * ktiles) return;
+    const int n = (int)(wid / ktiles), k = (int)(wid % ktiles) * 64 + lane;
+    const float *wr = w + (int64_t)min(k, classes - 1) * C;
+    const float *fr = feat + (int64_t)n * C;
+    // four independent chains (channel c goes to chain c mod 4), combined pairwise: short dependency chains for the issue
+    // rate and a summation error of the order of the tree the first form used
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+    int c = 0;
+    if ((C & 3) == 0) {
+        for (; c < C; c += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + c);
+            const f32x4 fv = *reinterpret_cast<const f32x4 *>(fr + c);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) logits[o] = s + b[k];
+            for (int i = 0; i < 4; ++i) s4[i] = fmaf(fv[i], wv[i], s4[i]);
+        }
+    }
+    for (; c < C; ++c) s4[c & 3] = fmaf(fr[c], wr[c], s4[c & 3]);
+    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    if (k < classes) logits[(int64_t)n * classes + k] = s + b[k];
 }
 
 extern "C" int csk_input_norm_f32(const float *x, const float *scale, const float *shift, float *h, int N, int C,
@@ -69,9 +84,11 @@ extern "C" int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_
                           int classes, void *stream) {
     if (!feat || !fc_w || !fc_b || !logits) CSK_FAIL("fc: null pointer");
     if (N <= 0 || C <= 0 || classes <= 0) CSK_FAIL("fc: bad dims");
-    const int64_t outs = (int64_t)N * classes;
-    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feat, fc_w, fc_b,
-                       logits, N, C, classes);
+    if ((reinterpret_cast<uintptr_t>(feat) & 15) || (reinterpret_cast<uintptr_t>(fc_w) & 15)) CSK_FAIL("fc: feat / fc_w must be 16-byte aligned");
+    const int ktiles = (classes + 63) / 64;
+    const int64_t waves = (int64_t)N * ktiles;
+    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feat, fc_w, fc_b,
+                       logits, N, C, classes, ktiles);
     return (int)hipGetLastError();
 }
 

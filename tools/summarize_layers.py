@@ -25,7 +25,7 @@ import workmodel as wm  # noqa: E402
 def short(name):
     for k in ("gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
               "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
-              "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "gcn_stage_dense_kernel", "gcn_stage_dense2_kernel"):
+              "agcn_embed_attention_step_kernel", "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "gcn_stage_dense_kernel", "gcn_stage_dense2_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
             return k + t
