@@ -64,13 +64,24 @@ class AdaptiveGraphConvolution(GraphConvolution):
         ops = self._packed_ops(x.device)
         n, c, t, v = x.shape
         e_ch = 6 * self.inter_c
+        y = torch.empty((n, self.out_channels, t, v), device=x.device, dtype=torch.float32)
+        if v == 18 and self.inter_c in (16, 32, 64) and x.data_ptr() % 8 == 0:
+            # embedding convs + partial logits in one launch, softmax in a second (csk_agcn_embed_attention_f32, per-segment form)
+            adj = torch.empty((n, 3, v, v), device=x.device, dtype=torch.float32)
+            scratch = torch.empty((n, 3, (t + 6) // 7, v, v), device=x.device, dtype=torch.float32)
+            rc = native.lib().csk_agcn_embed_attention_f32(
+                native.ptr(x), native.ptr(ops["w_embed_pairs"]), native.ptr(ops["b_embed_pairs"]), native.ptr(ops["a_sum"]),
+                native.ptr(adj), native.ptr(scratch), n, c, self.inter_c, t, v, 0, c * t * v, t * v, native.stream_of(x))
+            native.check(rc, "csk_agcn_embed_attention_f32")
+            blocks.gcn_stage(x, y, dict(ops, ell_val=adj), n_seg=n, frames=t, x_strides=(c * t * v, t * v),
+                             y_strides=(self.out_channels * t * v, t * v), adj_seg_stride=3 * v * v)
+            return y
         # (N, 6*inter, T, V), + 4 floats of slack behind it (csk_agcn_attention_f32 reads whole 16-byte vectors)
         E = torch.empty((n * e_ch * t * v + 4,), device=x.device, dtype=torch.float32)[: n * e_ch * t * v].view(n, e_ch, t, v)
         rc = native.lib().csk_conv1x1_f32(native.ptr(x), native.ptr(E), native.ptr(ops["w_embed"]), native.ptr(ops["b_embed"]), n, c,
                                           e_ch, t, v, c * t * v, t * v, e_ch * t * v, t * v, native.stream_of(x))
         native.check(rc, "csk_conv1x1_f32")
         adj = self._attention(E, ops, n, t, v, e_ch * t * v, t * v)
-        y = torch.empty((n, self.out_channels, t, v), device=x.device, dtype=torch.float32)
         o = dict(ops, ell_val=adj)
         blocks.gcn_stage(x, y, o, n_seg=n, frames=t, x_strides=(c * t * v, t * v),
                          y_strides=(self.out_channels * t * v, t * v), adj_seg_stride=3 * v * v)
@@ -85,12 +96,12 @@ class AdaptiveGraphConvolution(GraphConvolution):
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
         if v == 18 and self.inter_c in (16, 32, 64) and x.data_ptr() % 8 == 0 and x_strides[0] % 2 == 0 and p % 2 == 0:
-            # embedding convs + attention in one launch (csk_agcn_embed_attention_step_f32), then the graph conv
+            # embedding convs + attention in one launch (csk_agcn_embed_attention_f32, per-frame form), then the graph conv
             adj = torch.empty((n_seg * frames, 3, v, v), device=x.device, dtype=torch.float32)
-            rc = native.lib().csk_agcn_embed_attention_step_f32(
+            rc = native.lib().csk_agcn_embed_attention_f32(
                 native.ptr(x), native.ptr(ops["w_embed_pairs"]), native.ptr(ops["b_embed_pairs"]), native.ptr(ops["a_sum"]),
-                native.ptr(adj), n_seg, self.in_channels, self.inter_c, frames, v, x_strides[0], p, native.stream_of(x))
-            native.check(rc, "csk_agcn_embed_attention_step_f32")
+                native.ptr(adj), None, n_seg, self.in_channels, self.inter_c, frames, v, 1, x_strides[0], p, native.stream_of(x))
+            native.check(rc, "csk_agcn_embed_attention_f32")
             blocks.gcn_stage(x, y, dict(ops, ell_val=adj), n_seg=n_seg, frames=frames, x_strides=x_strides, y_strides=y_strides,
                              adj_seg_stride=3 * v * v, adj_per_frame=1)
             return

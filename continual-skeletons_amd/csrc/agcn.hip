@@ -202,7 +202,8 @@ extern "C" int csk_agcn_attention_f32(const float *E, const float *a_sum, float 
 }
 
 // ------------------------------------------------------------------------------------------------
-// CoAGCN step form, fused: embedding 1x1 convs + per-skeleton attention in ONE launch (no E tensor in memory).
+// Fused form: embedding 1x1 convs + attention logits in ONE launch (no E tensor in memory); step form (CoAGCN, one
+// attention per skeleton frame) and clip form (A-GCN, one attention per segment: partial logits per tile + a softmax launch).
 // A workgroup takes FT = 128 / V whole skeletons ("frames" of a channel-major slot) and NP (a_i, b_i) pairs:
 //   (1) E[rows][cols] = W_e . x + b_e for its 2 * INTER * NP embedding rows (pair-major row order: a_i rows, then b_i rows)
 //       as an fp32-MFMA GEMM over C_in -- a wave owns all rows x 32 columns, accumulator block i / MFMA row rho = tile row
@@ -214,15 +215,15 @@ extern "C" int csk_agcn_attention_f32(const float *E, const float *a_sum, float 
 // ------------------------------------------------------------------------------------------------
 struct EmbAttParams {
     const float *x, *w, *bias, *a_sum;
-    float *ell_val;
+    float *ell_val, *part;
     int64_t x_seg_stride, x_chan_stride;
     int Cin, CinPad, Mpad, frames;
     unsigned qtiles, mtiles;
 };
 typedef float f32x2a __attribute__((ext_vector_type(2)));
 
-template <int INTER, int NP, int VP>
-__global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_step_kernel(const EmbAttParams p) {
+template <int INTER, int NP, int VP, bool CLIP>
+__global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_kernel(const EmbAttParams p) {
     constexpr int V = 2 * VP, VPAD = (V + 3) & ~3, NT = 128, FT = NT / V;
     constexpr int MT = 2 * INTER * NP, NB = MT / 32;
     constexpr int KC2 = 16, NS = KC2 / 2, NH = NS / 2;
@@ -305,6 +306,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_step_kernel(
             if (s < NH) {
 #pragma unroll
                 for (int i = s * NL / NH; i < (s + 1) * NL / NH; ++i) issue_one(i, cnext);
+                // pinned to this k-step (left alone, the scheduler sinks the loads to the end of the block, right in front of
+                // the barrier and the commit that waits for them)
+                __builtin_amdgcn_sched_barrier(0);
             }
             const int kk = 2 * s + kh;
             const float b = cur[WSZ + kk * LDX + xcol];
@@ -324,9 +328,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_step_kernel(
             Es[row * ESLD + j] = acc[i][g] + p.bias[m0 + row];
         }
     __syncthreads();
-    // attention units (pair, skeleton) dealt to the waves
-    const float inv = 1.f / (float)INTER;
     const int cl = min(l31, V - 1);
+    if constexpr (CLIP) {
+        // clip form: ONE attention per segment over all its frames -- this tile contributes the partial logits of its
+        // frames, part[seg][pair][tile][v][w] = sum_{f, k} Ea[k][f, v] Eb[k][f, w]; agcn_softmax_parts_kernel sums the tiles
+        // in order.  Wave q takes frames f = q, q + 4, ...; the four partial 32 x 32 tiles are added through LDS in a
+        // fixed order (for NP = 1 the buffer aliases the E tile once everybody has read it).
+        float *red = NP == 1 ? smem_ea : smem_ea + MT * ESLD;                  // [4][32][33]
+#pragma unroll 1
+        for (int pr = 0; pr < NP; ++pr) {
+            f32x16 lg;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) lg[g] = 0.f;
+            for (int f = wave; f < fcnt; f += NTHREADS / 64) {
+                const float *ea = Es + (pr * 2 * INTER + kh) * ESLD + f * V + cl;
+                const float *eb = ea + INTER * ESLD;
+#pragma unroll 8
+                for (int s = 0; s < INTER / 2; ++s) lg = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[2 * s * ESLD], eb[2 * s * ESLD], lg, 0, 0, 0);
+            }
+            if (NP == 1) __syncthreads();                                       // all reads of the E tile are done
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + l31] = lg[r];
+            __syncthreads();
+            const int pi = mt * NP + pr;
+            float *dst = p.part + (((int64_t)seg * 3 + pi) * p.qtiles + qt) * (V * V);
+            for (int e = tid; e < V * V; e += NTHREADS) {
+                const int v = e / V, w = e - v * V;
+                dst[e] = ((red[(0 * 32 + v) * 33 + w] + red[(1 * 32 + v) * 33 + w]) + red[(2 * 32 + v) * 33 + w]) + red[(3 * 32 + v) * 33 + w];
+            }
+            if (NP > 1) __syncthreads();                                        // red is rewritten by the next pair
+        }
+    } else {
+    // step form: attention units (pair, skeleton) dealt to the waves
+    const float inv = 1.f / (float)INTER;
     const bool col = l31 < V;
     for (int u = wave; u < NP * fcnt; u += NTHREADS / 64) {
         const int pr = u / fcnt, f = u - pr * fcnt;
@@ -365,24 +399,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_step_kernel(
             }
         }
     }
+    }
 }
 
-template <int INTER, int NP>
+// adj[n][i][w][v] = softmax over v of (sum_tiles part[n][i][tile][v][w]) / K + (A + graph_attn)[i][v][w]; one workgroup per
+// (n, i): thread e = (v, w) sums its element over the tiles in order (coalesced), then lanes w < V do the softmax from LDS
+__global__ __launch_bounds__(NTHREADS) void agcn_softmax_parts_kernel(const float *__restrict__ part, const float *__restrict__ a_sum,
+                                                                      float *__restrict__ ell_val, int nparts, int K, int V) {
+    __shared__ float lg[32 * 33];
+    const int pair = blockIdx.x, i = pair % 3, tid = threadIdx.x;
+    const float *src = part + (int64_t)pair * nparts * V * V;
+    for (int e = tid; e < V * V; e += NTHREADS) {
+        float s = 0.f;
+        for (int t = 0; t < nparts; ++t) s += src[(int64_t)t * V * V + e];
+        lg[(e / V) * 33 + e % V] = s / (float)K;
+    }
+    __syncthreads();
+    if (tid < V) {
+        const int w = tid;
+        float m = -INFINITY;
+        for (int v = 0; v < V; ++v) m = fmaxf(m, lg[v * 33 + w]);
+        float sum = 0.f;
+        for (int v = 0; v < V; ++v) sum += expf(lg[v * 33 + w] - m);
+        float *dst = ell_val + ((int64_t)pair * V + w) * V;
+        for (int v = 0; v < V; ++v) dst[v] = expf(lg[v * 33 + w] - m) / sum + a_sum[(i * V + v) * V + w];
+    }
+}
+
+template <int INTER, int NP, bool CLIP>
 static int launch_embed_attention(EmbAttParams p, int n_seg, hipStream_t stream) {
     constexpr int VP = 9, V = 18, VPAD = 20, FT = 128 / V, MT = 2 * INTER * NP;
-    p.qtiles = (p.frames + FT - 1) / FT;
     p.mtiles = 3 / NP;
-    const size_t a = 2 * (size_t)(16 * MT + 16 * FT * VPAD), b = (size_t)MT * (128 + 4);
+    const size_t a = 2 * (size_t)(16 * MT + 16 * FT * VPAD), b = (size_t)MT * (128 + 4) + (CLIP && NP > 1 ? 4 * 32 * 33 : 0);
     const size_t lds = (a > b ? a : b) * sizeof(float);
-    void (*k)(EmbAttParams) = agcn_embed_attention_step_kernel<INTER, NP, VP>;
+    void (*k)(EmbAttParams) = agcn_embed_attention_kernel<INTER, NP, VP, CLIP>;
     if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(p.qtiles * p.mtiles * n_seg), dim3(NTHREADS), lds, stream, p);
     return (int)hipGetLastError();
 }
 
-extern "C" int csk_agcn_embed_attention_step_f32(const float *x, const float *w_pairs, const float *b_pairs, const float *a_sum,
-                                                 float *ell_val, int n_seg, int c_in, int inter, int frames, int V,
-                                                 int64_t x_seg_stride, int64_t x_chan_stride, void *stream) {
+extern "C" int csk_agcn_embed_attention_f32(const float *x, const float *w_pairs, const float *b_pairs, const float *a_sum,
+                                            float *ell_val, float *scratch, int n_seg, int c_in, int inter, int frames, int V,
+                                            int per_frame, int64_t x_seg_stride, int64_t x_chan_stride, void *stream) {
     if (!x || !w_pairs || !b_pairs || !a_sum || !ell_val) CSK_FAIL("agcn_embed_attention: null pointer");
     if (n_seg <= 0 || c_in <= 0 || frames <= 0) CSK_FAIL("agcn_embed_attention: bad dims");
     if (V != 18 || (inter != 16 && inter != 32 && inter != 64))
@@ -390,12 +448,24 @@ extern "C" int csk_agcn_embed_attention_step_f32(const float *x, const float *w_
     if ((reinterpret_cast<uintptr_t>(x) & 7) || (x_seg_stride & 1) || (x_chan_stride & 1))
         CSK_FAIL("agcn_embed_attention: activation rows must be 8-byte aligned");
     if ((int64_t)n_seg * frames >= (1ll << 31) / (3 * V * V)) CSK_FAIL("agcn_embed_attention: too many skeletons for one launch");
+    if (!per_frame && !scratch) CSK_FAIL("agcn_embed_attention: the per-segment form needs n_seg * 3 * ceil(frames / 7) * V * V floats of scratch");
     EmbAttParams p;
-    p.x = x; p.w = w_pairs; p.bias = b_pairs; p.a_sum = a_sum; p.ell_val = ell_val;
+    p.x = x; p.w = w_pairs; p.bias = b_pairs; p.a_sum = a_sum; p.ell_val = ell_val; p.part = scratch;
     p.x_seg_stride = x_seg_stride; p.x_chan_stride = x_chan_stride;
     p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD); p.Mpad = round_up(6 * inter, CSK_MT); p.frames = frames;
+    p.qtiles = (frames + 6) / 7;
     hipStream_t s = (hipStream_t)stream;
-    if (inter == 16) return launch_embed_attention<16, 3>(p, n_seg, s);
-    if (inter == 32) return launch_embed_attention<32, 1>(p, n_seg, s);
-    return launch_embed_attention<64, 1>(p, n_seg, s);
+    int rc;
+    if (per_frame) {
+        if (inter == 16) return launch_embed_attention<16, 3, false>(p, n_seg, s);
+        if (inter == 32) return launch_embed_attention<32, 1, false>(p, n_seg, s);
+        return launch_embed_attention<64, 1, false>(p, n_seg, s);
+    }
+    if (inter == 16) rc = launch_embed_attention<16, 3, true>(p, n_seg, s);
+    else if (inter == 32) rc = launch_embed_attention<32, 1, true>(p, n_seg, s);
+    else rc = launch_embed_attention<64, 1, true>(p, n_seg, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(agcn_softmax_parts_kernel, dim3(3 * n_seg), dim3(NTHREADS), 0, s, scratch, a_sum, ell_val, (int)p.qtiles,
+                       inter * frames, V);
+    return (int)hipGetLastError();
 }

@@ -27,7 +27,7 @@ SIGNATURES = {
     "csk_fc_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
     "csk_pool_scaled_f32": [_p, _p, _i, _i, _i, _i, C.c_float, _p],
     "csk_agcn_attention_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _l, _l, _i, _l, _p],
-    "csk_agcn_embed_attention_step_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _p],
+    "csk_agcn_embed_attention_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     "csk_tcn_step_f32": [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _p, _p],
     "csk_co_block_step_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _l, _p],
     "csk_co_spatial_pool_f32": [_p, _p, _i, _i, _i, _l, _p],

@@ -25,7 +25,7 @@ import workmodel as wm  # noqa: E402
 def short(name):
     for k in ("gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
               "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
-              "agcn_embed_attention_step_kernel", "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "gcn_stage_dense_kernel", "gcn_stage_dense2_kernel"):
+              "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel", "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "gcn_stage_dense_kernel", "gcn_stage_dense2_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
             return k + t
@@ -169,7 +169,8 @@ def main():
                 alg = ex = lw["embed_macs"]
                 cnt = lw["frames_in"]
             elif k == "a":
-                alg = ex = lw["attn_macs"]
+                # no separate embedding launch in this block: the fused kernel (agcn_embed_attention_kernel) did both
+                alg = ex = lw["attn_macs"] + (0 if pl["e"] else lw["embed_macs"])
                 cnt = lw["frames_in"]
             elif k == "g":
                 base = lw["gcn_macs"] - lw.get("embed_macs", 0) - lw.get("attn_macs", 0)
@@ -182,7 +183,7 @@ def main():
                 cnt = lw["emissions"]
             alg, ex = 2e-9 * alg * n_skel, 2e-9 * ex * n_skel
             tf = alg / avg
-            name = {"e": "embed 1x1", "a": "attention", "g": "gcn", "t": "tcn_stage" if clip else "tcn_step", "f": "fused"}[k]
+            name = {"e": "embed 1x1", "a": "attention" if pl["e"] else "embed + attention", "g": "gcn", "t": "tcn_stage" if clip else "tcn_step", "f": "fused"}[k]
             L.append(f"| L{i + 1} {lw['ci']}->{lw['co']} s{lw['stride']} | {name} | {cnt} | {len(pl[k])} | {avg:.4f} | {alg:.2f} ({ex:.2f}) | {tf:.1f} | {tf / peak:.3f} | {ex / avg:.1f} | {ex / avg / peak:.3f} |")
             csv_rows.append(dict(layer=i + 1, c_in=lw["ci"], c_out=lw["co"], stride=lw["stride"], stage=name, launches=len(pl[k]),
                                  avg_ms=round(avg, 5), gflop_alg=round(alg, 3), gflop_exec=round(ex, 3), tflops_alg=round(tf, 2),
