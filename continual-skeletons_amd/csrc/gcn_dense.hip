@@ -17,15 +17,19 @@
 // Per-segment and per-frame adjacencies differ only in the address the prologue loads a lane's column from.
 // Summation order over v: even and odd joints in separate fmaf chains, then one add (the general kernel of gcn.hip sums
 // v = 0, 1, 2, ...): same tolerance class as every other fp32 path here, NOT bitwise equal to gcn_stage_kernel.
-// Built for even V <= 18 (Kinetics / OpenPose-18, BASELINE configs[3]); other joint counts use gcn.hip.
+// Built for V = 18 (Kinetics / OpenPose-18, BASELINE configs[3]) and V = 25 (NTU RGB+D: 75 adjacency registers, joints staged
+// one by one because frames start at odd offsets); other joint counts use gcn.hip.
+#include <type_traits>
+
 #include "mfma_core.h"
 #include "gcn_params.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MT, bool CONVRES, int VP, int KC2>
+template <int MT, bool CONVRES, int V, int KC2>
 __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_dense2_kernel(const GcnParams p) {
-    constexpr int V = 2 * VP, VPAD = (V + 3) & ~3;       // joints, padded frame length in the LDS tile
+    constexpr int VP = (V + 1) / 2, VPAD = (V + 3) & ~3; // joint pairs (odd V: the last pair is half empty), padded frame length in LDS
+    constexpr bool EVEN = V % 2 == 0;
     constexpr int NT = 128, FT = NT / V;                 // tile columns (4 waves x 32), whole frames per tile
     constexpr int NB = MT / 32;                          // accumulator blocks of a wave
     constexpr int R = CONVRES ? 4 : 3;
@@ -33,9 +37,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_dense2_kernel(const Gcn
     constexpr int LDX = FT * VPAD;                       // x row length in LDS
     constexpr int M4 = MT / 4;
     constexpr int WB = (R * KC2 * M4 + NTHREADS - 1) / NTHREADS;   // f32x4 of weights per thread and chunk
-    constexpr int XB = KC2 * 64 / NTHREADS;              // f32x2 of activations per thread and chunk (64 pair slots per row)
+    constexpr int XSL = EVEN ? 64 : 128;                 // staging slots per activation row: joint pairs (even V) or joints
+    constexpr int XB = KC2 * XSL / NTHREADS;             // ... per thread and chunk
     constexpr int NL = WB + XB;
-    static_assert(FT * VP <= 64 && VPAD % 4 == 0 && V <= 18, "tile shape");
+    static_assert(FT * V <= NT && VPAD % 4 == 0 && V <= 26 && KC2 * XSL % NTHREADS == 0, "tile shape");
     constexpr int WSZ = R * KC2 * MT, BUFSZ = WSZ + KC2 * LDX;      // one chunk buffer: Wl [R][KC2][MT], Bx [KC2][LDX]
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -62,7 +67,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_dense2_kernel(const Gcn
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int i = 0; i < VP; ++i) {
-                const f32x2 a = *reinterpret_cast<const f32x2 *>(ab + r * V * V + 2 * i);
+                f32x2 a;
+                if constexpr (EVEN) {
+                    a = *reinterpret_cast<const f32x2 *>(ab + r * V * V + 2 * i);
+                } else {                                   // odd V: columns start at odd offsets; the last pair has one joint
+                    a[0] = ab[r * V * V + 2 * i];
+                    a[1] = 2 * i + 1 < V ? ab[r * V * V + min(2 * i + 1, V - 1)] : 0.f;
+                }
                 adj[r][i] = jv ? a : f32x2{0.f, 0.f};
             }
     }
@@ -85,29 +96,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_dense2_kernel(const Gcn
         wgo[u] = (unsigned)(((row / KC2) * p.CinPad + (row % KC2)) * p.Mpad + m4 * 4);
         wlo[u] = (unsigned)(e * 4);
     }
-    f32x2 xv2[XB];
+    // activation staging: joint pairs (8-byte loads; even V: every frame of a row starts 8-byte aligned) or single joints
+    typedef std::conditional_t<EVEN, f32x2, float> xs_t;
+    xs_t xv2[XB];
     unsigned xgo, xlo;
-    const int xrow0 = tid >> 6;                          // row of the first sweep; sweep u stages row xrow0 + 4 u
-    {
-        const int pr = min(tid & 63, fcnt * VP - 1);     // pair slot -> (frame, joint pair)
+    constexpr int RPS = NTHREADS / XSL;                  // rows per sweep
+    const int xrow0 = tid / XSL;                         // row of the first sweep; sweep u stages row xrow0 + RPS u
+    if constexpr (EVEN) {
+        const int pr = min(tid % XSL, fcnt * VP - 1);    // pair slot -> (frame, joint pair)
         const int f = pr / VP, w2 = pr - f * VP;
         xgo = (unsigned)(q0 + 2 * pr);
         xlo = (unsigned)(f * VPAD + 2 * w2);
+    } else {
+        const int e = min(tid % XSL, ncol - 1);          // joint slot -> (frame, joint)
+        const int f = e / V;
+        xgo = (unsigned)(q0 + e);
+        xlo = (unsigned)(f * VPAD + (e - f * V));
     }
     auto issue_one = [&](int i, int c0) {
         if (i < WB) {
             wv[i] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)c0 * p.Mpad + wgo[i]);
         } else {
-            const int c = min(c0 + xrow0 + 4 * (i - WB), p.Cin - 1);         // clamped: padding channels carry zero weights
-            xv2[i - WB] = *reinterpret_cast<const f32x2 *>(seg_base + (int64_t)c * p.x_chan_stride + xgo);
+            const int c = min(c0 + xrow0 + RPS * (i - WB), p.Cin - 1);       // clamped: padding channels carry zero weights
+            xv2[i - WB] = *reinterpret_cast<const xs_t *>(seg_base + (int64_t)c * p.x_chan_stride + xgo);
         }
     };
     auto commit = [&](float *buf) {
 #pragma unroll
         for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(buf + wlo[u]) = wv[u];
 #pragma unroll
-        for (int u = 0; u < XB; ++u) *reinterpret_cast<f32x2 *>(buf + WSZ + (xrow0 + 4 * u) * LDX + xlo) = xv2[u];
+        for (int u = 0; u < XB; ++u) *reinterpret_cast<xs_t *>(buf + WSZ + (xrow0 + RPS * u) * LDX + xlo) = xv2[u];
     };
+    if constexpr (!EVEN) {
+        // odd V: the half-empty last joint pair multiplies the frame's first padding slot by a zero weight -- keep it finite
+        for (int e = tid; e < 2 * KC2 * FT; e += NTHREADS) {
+            const int b = e / (KC2 * FT), r = e % (KC2 * FT);
+            smem[b * BUFSZ + WSZ + (r / FT) * LDX + (r % FT) * VPAD + V] = 0.f;
+        }
+    }
     // One MFMA k-step (operands in registers) with the NEXT k-step's operands formed between its MFMAs: a wave issues in
     // order, so the vector-ALU / LDS work has to sit between the MFMAs in program order to run in their shadow
     // (sched_barrier pins the order; left to itself the scheduler emits the MFMAs back to back and the rest behind them).
@@ -266,31 +292,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_dense2_kernel(const Gcn
     }
 }
 
-template <int MT, bool CONVRES, int VP, int KC2>
+template <int MT, bool CONVRES, int V, int KC2>
 static int launch_dense2(const GcnParams &p, int n_seg, hipStream_t stream) {
-    constexpr int V = 2 * VP, VPAD = (V + 3) & ~3, FT = 128 / V, R = CONVRES ? 4 : 3;
+    constexpr int VPAD = (V + 3) & ~3, FT = 128 / V, R = CONVRES ? 4 : 3;
     const size_t lds = 2 * (size_t)(R * KC2 * MT + KC2 * FT * VPAD) * sizeof(float);
-    void (*k)(GcnParams) = gcn_stage_dense2_kernel<MT, CONVRES, VP, KC2>;
+    void (*k)(GcnParams) = gcn_stage_dense2_kernel<MT, CONVRES, V, KC2>;
     if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(p.qtiles * p.mtiles * n_seg), dim3(NTHREADS), lds, stream, p);
     return (int)hipGetLastError();
 }
 
-int csk_launch_gcn_dense2(GcnParams p, int n_seg, void *stream) {
-    // even V (pairs of joints are the unit of staging and of the packed FMAs) up to 18; 8-byte aligned activation rows
-    if (!p.dense || p.V != 18) return -2;
-    if ((reinterpret_cast<uintptr_t>(p.x) & 7) || (p.x_seg_stride & 1) || (p.x_chan_stride & 1)) return -2;
-    if ((reinterpret_cast<uintptr_t>(p.ell_val) & 7) || (p.adj_seg_stride & 1)) return -2;
-    if (p.frames < 1) return -2;
-    constexpr int VP = 9, FT = 128 / 18;
+template <int V>
+static int dispatch_dense2(GcnParams p, int n_seg, hipStream_t s) {
+    constexpr int FT = 128 / V;
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64;
     p.lds_frames = FT;
     p.qtiles = (p.frames + FT - 1) / FT;
     p.mtiles = p.Mpad / MT;
     if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) return -2;
-    hipStream_t s = (hipStream_t)stream;
     // (16-channel chunks -- one barrier per 96 / 48 MFMAs -- measured equal on clips and 3 % slower online: 8 it is)
-    if (big) return p.R == 4 ? launch_dense2<128, true, VP, 8>(p, n_seg, s) : launch_dense2<128, false, VP, 8>(p, n_seg, s);
-    return p.R == 4 ? launch_dense2<64, true, VP, 8>(p, n_seg, s) : launch_dense2<64, false, VP, 8>(p, n_seg, s);
+    if (big) return p.R == 4 ? launch_dense2<128, true, V, 8>(p, n_seg, s) : launch_dense2<128, false, V, 8>(p, n_seg, s);
+    return p.R == 4 ? launch_dense2<64, true, V, 8>(p, n_seg, s) : launch_dense2<64, false, V, 8>(p, n_seg, s);
+}
+
+int csk_launch_gcn_dense2(GcnParams p, int n_seg, void *stream) {
+    // built for the two skeleton layouts of the reference's datasets: V = 18 (Kinetics / OpenPose) and V = 25 (NTU RGB+D)
+    if (!p.dense || (p.V != 18 && p.V != 25) || p.frames < 1) return -2;
+    if (p.V % 2 == 0) {   // joint pairs are staged with 8-byte loads
+        if ((reinterpret_cast<uintptr_t>(p.x) & 7) || (p.x_seg_stride & 1) || (p.x_chan_stride & 1)) return -2;
+        if ((reinterpret_cast<uintptr_t>(p.ell_val) & 7) || (p.adj_seg_stride & 1)) return -2;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    return p.V == 18 ? dispatch_dense2<18>(p, n_seg, s) : dispatch_dense2<25>(p, n_seg, s);
 }

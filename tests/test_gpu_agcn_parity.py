@@ -43,9 +43,10 @@ def _randomise(m, seed):
 
 
 # V = 18: gcn_stage_dense2_kernel (on-the-fly dense aggregation; 64- and 128-row tiles, identity and conv residual, a last tile
-# of 1 ... 6 frames, C_out below the tile height); V = 25: the kernels of gcn.hip
+# of 1 ... 6 frames, C_out below the tile height), also at V = 25 (odd: joints staged one by one, half-empty last pair)
 @pytest.mark.parametrize("ci,co,t,v", [(64, 64, 40, 18), (64, 128, 17, 18), (3, 64, 300, 18), (16, 16, 9, 25), (128, 128, 10, 18),
-                                       (256, 256, 15, 18), (16, 24, 9, 18), (128, 256, 1, 18), (40, 40, 7, 18)])
+                                       (256, 256, 15, 18), (16, 24, 9, 18), (128, 256, 1, 18), (40, 40, 7, 18),
+                                       (128, 128, 11, 25), (64, 128, 7, 25), (256, 256, 4, 25)])
 def test_adaptive_graph_conv_vs_oracle(ci, co, t, v):
     A = A_KIN if v == 18 else pkg.ntu_graph().A
     m = pkg.AdaptiveGraphConvolution(ci, co, A).eval()
@@ -57,17 +58,20 @@ def test_adaptive_graph_conv_vs_oracle(ci, co, t, v):
     check_parity(got, want, shape=(ci, co, t, v))
 
 
-def test_agcn_block_clip_and_continual():
+@pytest.mark.parametrize("graph,c", [("kinetics", 8), ("kinetics", 128), ("ntu", 8), ("ntu", 64)])
+def test_agcn_block_clip_and_continual(graph, c):
     """SpatioTemporalBlock(GraphConv=AdaptiveGraphConvolution) in clip mode, and the CoAGCN block stepping
-    (per-frame attention) against the oracle's continual block built on adaptive_graph_conv."""
-    blk = pkg.SpatioTemporalBlock(8, 8, A_KIN, GraphConv=pkg.AdaptiveGraphConvolution).eval()
+    (per-frame attention) against the oracle's continual block built on adaptive_graph_conv.  (c = 64: the fused embedding +
+    attention launch on the Kinetics graph; the NTU graph keeps the two-launch route and gcn_stage_dense2_kernel<.., 25>.)"""
+    A_KIN = pkg.kinetics_graph().A if graph == "kinetics" else pkg.ntu_graph().A
+    blk = pkg.SpatioTemporalBlock(c, c, A_KIN, GraphConv=pkg.AdaptiveGraphConvolution).eval()
     _randomise(blk, 3)
     sd = {k: v.clone() for k, v in blk.state_dict().items()}
-    x = torch.rand(2, 8, 24, 18, generator=torch.Generator().manual_seed(9))
+    x = torch.rand(2, c, 24, A_KIN.shape[-1], generator=torch.Generator().manual_seed(9))
     with torch.no_grad():
         want = o.st_block(x, sd, "", 1, True, gcn=o.adaptive_graph_conv)
     check_parity(blk.to(DEV)(x.to(DEV)).cpu(), want)
-    co = pkg.CoSpatioTemporalBlock(8, 8, A_KIN, padding=4, CoGraphConv=pkg.CoAdaptiveGraphConvolution).eval()
+    co = pkg.CoSpatioTemporalBlock(c, c, A_KIN, padding=4, CoGraphConv=pkg.CoAdaptiveGraphConvolution).eval()
     co.load_state_dict(sd, strict=True)
     co = co.to(DEV)
     orc = o.CoBlockOracle(sd, "", 1, True, padding=4, gcn=o.adaptive_graph_conv)
