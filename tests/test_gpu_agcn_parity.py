@@ -58,6 +58,20 @@ def test_adaptive_graph_conv_vs_oracle(ci, co, t, v):
     check_parity(got, want, shape=(ci, co, t, v))
 
 
+def test_adaptive_graph_conv_other_joint_counts():
+    """A skeleton layout that is neither Kinetics nor NTU (V = 20, a random 3-subset adjacency): the dense kernels of gcn.hip
+    (gcn_stage_dense_kernel for 128-row tiles, gcn_stage_kernel for 64-row ones) instead of gcn_dense.hip."""
+    g = torch.Generator().manual_seed(21)
+    A = (torch.rand(3, 20, 20, generator=g) < 0.2).float() * torch.rand(3, 20, 20, generator=g)
+    for ci, co, t in ((128, 128, 9), (32, 64, 13)):
+        m = pkg.AdaptiveGraphConvolution(ci, co, A).eval()
+        _randomise(m, 5 + ci)
+        sd = {k: v_.clone() for k, v_ in m.state_dict().items()}
+        x = torch.rand(2, ci, t, 20, generator=torch.Generator().manual_seed(6))
+        want = unit_scale_(m, sd, lambda s: o.adaptive_graph_conv(x, s), GCN_OUT_KEYS)
+        check_parity(m.to(DEV)(x.to(DEV)).cpu(), want, shape=(ci, co, t, 20))
+
+
 @pytest.mark.parametrize("graph,c", [("kinetics", 8), ("kinetics", 128), ("ntu", 8), ("ntu", 64)])
 def test_agcn_block_clip_and_continual(graph, c):
     """SpatioTemporalBlock(GraphConv=AdaptiveGraphConvolution) in clip mode, and the CoAGCN block stepping
