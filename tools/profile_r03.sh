@@ -20,7 +20,7 @@ for sh in 1 2; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/agcn_clip" -- python3 "$R/tools/agcn_prof.py" 64 6 > "$out/agcn_clip.log" 2>&1
 grep AGCN_PASS "$out/agcn_clip.log"
-for sh in 1 2; do
+for sh in 1 2 3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/coagcn$sh" -- python3 "$R/tools/online_pass.py" --model coagcn --shards $sh --cycles 16 > "$out/coagcn$sh.log" 2>&1
   grep ONLINE_PASS "$out/coagcn$sh.log"
 done

@@ -21,7 +21,8 @@ def rows_of(pattern):
 
 
 def short(name):
-    for k in ("tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
+    for k in ("tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
+              "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel",
               "agcn_logits_partial_kernel", "agcn_softmax_kernel", "input_norm_kernel", "pool_kernel", "fc_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
