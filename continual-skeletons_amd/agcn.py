@@ -87,6 +87,14 @@ class AdaptiveGraphConvolution(GraphConvolution):
                          y_strides=(self.out_channels * t * v, t * v), adj_seg_stride=3 * v * v)
         return y
 
+    def plan_operands(self, device):
+        """Operands of the native step executor (csk_co_layer.agcn_*: the per-frame form of csk_agcn_embed_attention_f32), or
+        None where that entry is not built (V != 18, inter not in {16, 32, 64}): such stacks keep the Python engine."""
+        ops = self._packed_ops(device)
+        if ops["V"] != 18 or self.inter_c not in (16, 32, 64):
+            return None
+        return dict(inter=self.inter_c, w_pairs=ops["w_embed_pairs"], b_pairs=ops["b_embed_pairs"], a_sum=ops["a_sum"])
+
     def stage(self, x, y, n_seg, frames, x_strides, y_strides):
         """Continual use on channel-major frames (C, P): every skeleton is its own 'sample' with T = 1, so the
         attention is computed per skeleton and frame (coa_gcn.py: forward_stepping of the module) and the graph

@@ -570,25 +570,42 @@ class CoStGcn(_Folded):
             for j in range(3):
                 L.ell_cnt[j] = int(g["ell_cnt_host"][j])
             L.gcn_w, L.gcn_bias = g["w"].data_ptr(), g["bias"].data_ptr()
-            L.ell_src, L.ell_val = g["ell_src"].data_ptr(), g["ell_val"].data_ptr()
+            L.ell_src = g["ell_src"].data_ptr()
+            L.ell_val = g["ell_val"].data_ptr() if g["ell_val"] is not None else None
             L.tcn_w, L.tcn_bias = t["w"].data_ptr(), t["bias"].data_ptr()
             L.tcn_w_res = t["w_res"].data_ptr() if t["w_res"] is not None else None
             L.y_ring, L.out_ring = st.y.data_ptr(), st.out.data_ptr()
             L.tcn_ksplit = st.ksplit
             L.tcn_partial = st.partial.data_ptr() if st.partial is not None else None
+            L.agcn_inter = 0
+            if type(blk.gcn) is not GraphConvolution:      # adaptive graph conv: adjacency per skeleton frame (agcn.py)
+                a = blk.gcn.plan_operands(device)
+                adj = self.__dict__.get("_agcn_adj")
+                need = MAX_CYCLE * self._n * self.input_shape[3] * 3 * self.input_shape[2] ** 2      # [cycle frames][skeletons][3][V][V]
+                if adj is None or adj.numel() < need or adj.device != st.y.device:
+                    adj = self.__dict__["_agcn_adj"] = torch.empty((need,), device=st.y.device, dtype=torch.float32)
+                L.agcn_inter = a["inter"]
+                L.agcn_w_pairs, L.agcn_b_pairs, L.agcn_a_sum = a["w_pairs"].data_ptr(), a["b_pairs"].data_ptr(), a["a_sum"].data_ptr()
+                L.agcn_adj = adj.data_ptr()
+                L.ell_val = None
         ops = self._packed_ops(device)
         fcw, fcb = self.fc.weight.detach(), self.fc.bias.detach()
         keep += [ops, fcw, fcb]
         return arr, keep, ops, fcw, fcb
 
     def _build_plan(self, device):
-        """csk_co_plan (include/cskel.h): one C call per cycle instead of ~25 ctypes calls.  Built for stacks of
-        plain GraphConvolution blocks; other graph convs (A-GCN) keep the Python engine below."""
+        """csk_co_plan (include/cskel.h): one C call per cycle instead of ~25 (CoAGCN: ~45) ctypes calls.  Built for stacks of
+        plain GraphConvolution blocks and of adaptive graph convs in the shapes the fused embedding + attention entry
+        covers (``plan_operands``); other graph convs keep the Python engine below."""
         self._destroy_plan()
         if not self.use_native_plan:
             return
-        if not all(type(self.layers[f"layer{i + 1}"].gcn) is GraphConvolution for i in range(10)):
-            return
+        for i in range(10):
+            gcn = self.layers[f"layer{i + 1}"].gcn
+            if type(gcn) is GraphConvolution:
+                continue
+            if getattr(gcn, "plan_operands", None) is None or gcn.plan_operands(device) is None:
+                return
         c, _, v, m = self.input_shape
         arr, keep, ops, fcw, fcb = self._layer_structs(device)
         plan = native.lib().csk_co_plan_create(10, ctypes.byref(arr), native.ptr(self._xin0), self._n, c, v, m, self._p,

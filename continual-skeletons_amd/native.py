@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 # name -> argtypes; mirrors include/cskel.h line by line
@@ -51,7 +51,9 @@ class CoLayer(C.Structure):
                 ("gcn_res_mode", C.c_int32), ("ell_w", C.c_int32), ("ell_cnt", C.c_int32 * 3), ("tcn_ksplit", C.c_int32),
                 ("gcn_w", C.c_void_p), ("gcn_bias", C.c_void_p), ("ell_src", C.c_void_p), ("ell_val", C.c_void_p),
                 ("tcn_w", C.c_void_p), ("tcn_w_res", C.c_void_p), ("tcn_bias", C.c_void_p),
-                ("y_ring", C.c_void_p), ("out_ring", C.c_void_p), ("tcn_partial", C.c_void_p)]
+                ("y_ring", C.c_void_p), ("out_ring", C.c_void_p), ("tcn_partial", C.c_void_p),
+                ("agcn_inter", C.c_int32), ("agcn_pad_", C.c_int32), ("agcn_w_pairs", C.c_void_p), ("agcn_b_pairs", C.c_void_p),
+                ("agcn_a_sum", C.c_void_p), ("agcn_adj", C.c_void_p)]
 
 
 _lib = None

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 10
+#define CSK_ABI_VERSION 11
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -298,6 +298,13 @@ typedef struct csk_co_layer {
     float *y_ring;                           /* [CSK_CO_YRING][c_out][P]                                   */
     float *out_ring;                         /* [CSK_CO_HIST][c_out][P]; input history of the next layer   */
     float *tcn_partial;                      /* [CSK_CO_MAX_CYCLE * tcn_ksplit][c_out][P] or NULL (tcn_ksplit == 1) */
+    /* adaptive graph conv (CoAGCN, models/coa_gcn/coa_gcn.py:11-14); agcn_inter == 0: plain GraphConvolution.  Otherwise the
+     * layer's adjacency is computed per skeleton frame by csk_agcn_embed_attention_f32 (per-frame form) into agcn_adj
+     * ([CSK_CO_MAX_CYCLE * skeletons][3][V][V] floats, may be shared by all layers: launches are stream-ordered) and ell_src /
+     * ell_w / ell_cnt describe the dense pattern (ell_w = V, ell_cnt = {V, V, V}); ell_val is not used. */
+    int32_t agcn_inter, agcn_pad_;
+    const float *agcn_w_pairs, *agcn_b_pairs, *agcn_a_sum;
+    float *agcn_adj;
 } csk_co_layer;
 
 typedef struct csk_co_plan csk_co_plan;

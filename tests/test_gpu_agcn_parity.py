@@ -98,9 +98,13 @@ def test_agcn_block_clip_and_continual(graph, c):
                 check_parity(g.cpu(), w, note=t)
 
 
-def test_coagcn_model_steps_vs_oracle():
+@pytest.mark.parametrize("native_plan", [True, False])
+def test_coagcn_model_steps_vs_oracle(native_plan):
+    """The whole CoAGCN stack stepping against the oracle: through the native step executor (csk_co_plan with the adaptive
+    graph-conv operands) and with every launch driven from Python -- the two must also agree bit for bit."""
     A = A_KIN
     net = pkg.CoAGcn(A, input_shape=(3, 300, 18, 2), num_classes=400, pool_size=4, pool_padding=1).eval()
+    net.use_native_plan = native_plan
     randomise_unit_(net, 11, attn_scale=1 / 18)         # O(1) activations through all ten blocks
     net_sd = net.state_dict()
     sd = {k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in net_sd.items()}
@@ -116,9 +120,17 @@ def test_coagcn_model_steps_vs_oracle():
                 want.append(r)
     net = net.to(DEV)
     got = net.forward_steps(x.to(DEV)).cpu()
+    assert bool(net.__dict__.get("_plan")) == native_plan
     want = torch.stack(want, dim=2)
     assert got.shape == want.shape and got.shape[2] >= 2
     check_parity(got, want)
+    if native_plan:                                     # same kernels, same launches: the Python engine gives the same bits
+        net.use_native_plan = False
+        net._n = None                                   # re-bind (clean state, no plan)
+        assert torch.equal(net.forward_steps(x.to(DEV)).cpu(), got) and not net.__dict__.get("_plan")
+        net.use_native_plan = True
+        net._n = None
+        net.forward_steps(x.to(DEV))
     net.clean_state()                                   # the same frames in 4-frame cycles (multi-slot GCN stage)
     xd = x.to(DEV)
     cyc = []
