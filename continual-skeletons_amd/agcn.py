@@ -65,10 +65,13 @@ class AdaptiveGraphConvolution(GraphConvolution):
         n, c, t, v = x.shape
         e_ch = 6 * self.inter_c
         y = torch.empty((n, self.out_channels, t, v), device=x.device, dtype=torch.float32)
-        if v == 18 and self.inter_c in (16, 32, 64) and x.data_ptr() % 8 == 0:
+        # (V = 25: the fused clip form measured SLOWER than GEMM + logits kernels -- 28.0 vs 24.2 ms per NTU batch-64 forward: five
+        # frames per tile, joints staged one by one -- so it is used at V = 18 only; the step form gains 4 % at V = 25 too)
+        if v == 18 and self._fused_ok(v, x.data_ptr(), c * t * v, t * v):
             # embedding convs + partial logits in one launch, softmax in a second (csk_agcn_embed_attention_f32, per-segment form)
             adj = torch.empty((n, 3, v, v), device=x.device, dtype=torch.float32)
-            scratch = torch.empty((n, 3, (t + 6) // 7, v, v), device=x.device, dtype=torch.float32)
+            ft = 128 // v                              # frames per tile of the kernel
+            scratch = torch.empty((n, 3, (t + ft - 1) // ft, v, v), device=x.device, dtype=torch.float32)
             rc = native.lib().csk_agcn_embed_attention_f32(
                 native.ptr(x), native.ptr(ops["w_embed_pairs"]), native.ptr(ops["b_embed_pairs"]), native.ptr(ops["a_sum"]),
                 native.ptr(adj), native.ptr(scratch), n, c, self.inter_c, t, v, 0, c * t * v, t * v, native.stream_of(x))
@@ -87,11 +90,19 @@ class AdaptiveGraphConvolution(GraphConvolution):
                          y_strides=(self.out_channels * t * v, t * v), adj_seg_stride=3 * v * v)
         return y
 
+    fuse_embed_attention = True     # False: two launches (csk_conv1x1_f32 + csk_agcn_attention_f32) -- for A/B measurements
+
+    def _fused_ok(self, v, data_ptr, seg_stride, chan_stride):
+        """Shapes csk_agcn_embed_attention_f32 is built for (even V: 8-byte aligned activation rows)."""
+        if not self.fuse_embed_attention or v not in (18, 25) or self.inter_c not in (16, 32, 64):
+            return False
+        return v % 2 == 1 or (data_ptr % 8 == 0 and seg_stride % 2 == 0 and chan_stride % 2 == 0)
+
     def plan_operands(self, device):
         """Operands of the native step executor (csk_co_layer.agcn_*: the per-frame form of csk_agcn_embed_attention_f32), or
-        None where that entry is not built (V != 18, inter not in {16, 32, 64}): such stacks keep the Python engine."""
+        None where that entry is not built (V not in {18, 25}, inter not in {16, 32, 64}): such stacks keep the Python engine."""
         ops = self._packed_ops(device)
-        if ops["V"] != 18 or self.inter_c not in (16, 32, 64):
+        if not self.fuse_embed_attention or ops["V"] not in (18, 25) or self.inter_c not in (16, 32, 64):
             return None
         return dict(inter=self.inter_c, w_pairs=ops["w_embed_pairs"], b_pairs=ops["b_embed_pairs"], a_sum=ops["a_sum"])
 
@@ -103,7 +114,7 @@ class AdaptiveGraphConvolution(GraphConvolution):
         ops = self._packed_ops(x.device)
         v, p = ops["V"], x_strides[1]
         e_ch = 6 * self.inter_c
-        if v == 18 and self.inter_c in (16, 32, 64) and x.data_ptr() % 8 == 0 and x_strides[0] % 2 == 0 and p % 2 == 0:
+        if self._fused_ok(v, x.data_ptr(), x_strides[0], p):
             # embedding convs + attention in one launch (csk_agcn_embed_attention_f32, per-frame form), then the graph conv
             adj = torch.empty((n_seg * frames, 3, v, v), device=x.device, dtype=torch.float32)
             rc = native.lib().csk_agcn_embed_attention_f32(

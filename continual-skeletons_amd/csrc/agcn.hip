@@ -1,4 +1,6 @@
 // agcn.hip -- A-GCN adaptive adjacency (models/a_gcn/a_gcn.py:53-63) on gfx950.
+#include <type_traits>
+
 #include "mfma_core.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -211,7 +213,8 @@ extern "C" int csk_agcn_attention_f32(const float *E, const float *a_sum, float 
 //   (2) the E tile goes to LDS; per (pair, skeleton) one wave forms logits = Ea^T . Eb (INTER / 2 MFMAs), the softmax over v
 //       in registers and writes adj[skeleton][i][w][v] -- the arithmetic of agcn_attention_step_kernel above, operand for
 //       operand (the E values equal csk_conv1x1_f32's: channels are accumulated in the same order).
-// Even V <= 18 (pairs of joints are the staging unit), INTER in {16, 32, 64}; other shapes take the two-launch route.
+// V in {18, 25} (even V: pairs of joints are the staging unit; odd V: single joints), INTER in {16, 32, 64}; other shapes take
+// the two-launch route.
 // ------------------------------------------------------------------------------------------------
 struct EmbAttParams {
     const float *x, *w, *bias, *a_sum;
@@ -222,16 +225,18 @@ struct EmbAttParams {
 };
 typedef float f32x2a __attribute__((ext_vector_type(2)));
 
-template <int INTER, int NP, int VP, bool CLIP>
+template <int INTER, int NP, int V, bool CLIP>
 __global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_kernel(const EmbAttParams p) {
-    constexpr int V = 2 * VP, VPAD = (V + 3) & ~3, NT = 128, FT = NT / V;
+    constexpr int VP = V / 2, VPAD = (V + 3) & ~3, NT = 128, FT = NT / V;
+    constexpr bool EVEN = V % 2 == 0;                     // joint pairs staged with 8-byte loads; odd V: joint by joint
+    constexpr int XSL = EVEN ? 64 : 128, RPS = NTHREADS / XSL;
     constexpr int MT = 2 * INTER * NP, NB = MT / 32;
     constexpr int KC2 = 16, NS = KC2 / 2, NH = NS / 2;
     constexpr int LDX = FT * VPAD, M4 = MT / 4;
-    constexpr int WB = (KC2 * M4 + NTHREADS - 1) / NTHREADS, XB = KC2 * 64 / NTHREADS, NL = WB + XB;
+    constexpr int WB = (KC2 * M4 + NTHREADS - 1) / NTHREADS, XB = KC2 * XSL / NTHREADS, NL = WB + XB;
     constexpr int WSZ = KC2 * MT, BUFSZ = WSZ + KC2 * LDX;
     constexpr int ESLD = NT + 4;                          // E tile row stride
-    static_assert(MT % 32 == 0 && FT * VP <= 64 && INTER % 2 == 0, "tile shape");
+    static_assert(MT % 32 == 0 && FT * V <= NT && V <= 32 && INTER % 2 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) float smem_ea[];      // max(2 * BUFSZ, MT * ESLD) floats
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,28 +270,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_kernel(const
         wgo[u] = (unsigned)(row * p.Mpad + m4 * 4);
         wlo[u] = (unsigned)(e * 4);
     }
-    f32x2a xv2[XB];
+    typedef std::conditional_t<EVEN, f32x2a, float> xs_t;
+    xs_t xv2[XB];
     unsigned xgo, xlo;
-    const int xrow0 = tid >> 6;
-    {
-        const int pr = min(tid & 63, fcnt * VP - 1);
+    const int xrow0 = tid / XSL;
+    if constexpr (EVEN) {
+        const int pr = min(tid % XSL, fcnt * VP - 1);
         const int f = pr / VP, w2 = pr - f * VP;
         xgo = (unsigned)(q0 + 2 * pr);
         xlo = (unsigned)(f * VPAD + 2 * w2);
+    } else {
+        const int e = min(tid % XSL, ncol - 1);
+        const int f = e / V;
+        xgo = (unsigned)(q0 + e);
+        xlo = (unsigned)(f * VPAD + (e - f * V));
     }
     auto issue_one = [&](int i, int c0) {
         if (i < WB) {
             wv[i] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)c0 * p.Mpad + wgo[i]);
         } else {
-            const int c = min(c0 + xrow0 + 4 * (i - WB), p.Cin - 1);         // clamped: padding channels carry zero weights
-            xv2[i - WB] = *reinterpret_cast<const f32x2a *>(seg_base + (int64_t)c * p.x_chan_stride + xgo);
+            const int c = min(c0 + xrow0 + RPS * (i - WB), p.Cin - 1);       // clamped: padding channels carry zero weights
+            xv2[i - WB] = *reinterpret_cast<const xs_t *>(seg_base + (int64_t)c * p.x_chan_stride + xgo);
         }
     };
     auto commit = [&](float *buf) {
 #pragma unroll
         for (int u = 0; u < WB; ++u) *reinterpret_cast<f32x4 *>(buf + wlo[u]) = wv[u];
 #pragma unroll
-        for (int u = 0; u < XB; ++u) *reinterpret_cast<f32x2a *>(buf + WSZ + (xrow0 + 4 * u) * LDX + xlo) = xv2[u];
+        for (int u = 0; u < XB; ++u) *reinterpret_cast<xs_t *>(buf + WSZ + (xrow0 + RPS * u) * LDX + xlo) = xv2[u];
     };
     const int nchunks = p.CinPad / KC2;
 #pragma unroll
@@ -426,13 +437,14 @@ __global__ __launch_bounds__(NTHREADS) void agcn_softmax_parts_kernel(const floa
     }
 }
 
-template <int INTER, int NP, bool CLIP>
+template <int INTER, int NP, int V, bool CLIP>
 static int launch_embed_attention(EmbAttParams p, int n_seg, hipStream_t stream) {
-    constexpr int VP = 9, V = 18, VPAD = 20, FT = 128 / V, MT = 2 * INTER * NP;
+    constexpr int VPAD = (V + 3) & ~3, FT = 128 / V, MT = 2 * INTER * NP;
     p.mtiles = 3 / NP;
+    p.qtiles = (p.frames + FT - 1) / FT;
     const size_t a = 2 * (size_t)(16 * MT + 16 * FT * VPAD), b = (size_t)MT * (128 + 4) + (CLIP && NP > 1 ? 4 * 32 * 33 : 0);
     const size_t lds = (a > b ? a : b) * sizeof(float);
-    void (*k)(EmbAttParams) = agcn_embed_attention_kernel<INTER, NP, VP, CLIP>;
+    void (*k)(EmbAttParams) = agcn_embed_attention_kernel<INTER, NP, V, CLIP>;
     if (const int e = csk_ensure_lds((const void *)k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(p.qtiles * p.mtiles * n_seg), dim3(NTHREADS), lds, stream, p);
     return (int)hipGetLastError();
@@ -443,29 +455,28 @@ extern "C" int csk_agcn_embed_attention_f32(const float *x, const float *w_pairs
                                             int per_frame, int64_t x_seg_stride, int64_t x_chan_stride, void *stream) {
     if (!x || !w_pairs || !b_pairs || !a_sum || !ell_val) CSK_FAIL("agcn_embed_attention: null pointer");
     if (n_seg <= 0 || c_in <= 0 || frames <= 0) CSK_FAIL("agcn_embed_attention: bad dims");
-    if (V != 18 || (inter != 16 && inter != 32 && inter != 64))
-        CSK_FAIL("agcn_embed_attention: built for V = 18 and inter in {16, 32, 64} (use csk_conv1x1_f32 + csk_agcn_attention_f32)");
-    if ((reinterpret_cast<uintptr_t>(x) & 7) || (x_seg_stride & 1) || (x_chan_stride & 1))
+    if ((V != 18 && V != 25) || (inter != 16 && inter != 32 && inter != 64))
+        CSK_FAIL("agcn_embed_attention: built for V in {18, 25} and inter in {16, 32, 64} (use csk_conv1x1_f32 + csk_agcn_attention_f32)");
+    if (V % 2 == 0 && ((reinterpret_cast<uintptr_t>(x) & 7) || (x_seg_stride & 1) || (x_chan_stride & 1)))
         CSK_FAIL("agcn_embed_attention: activation rows must be 8-byte aligned");
     if ((int64_t)n_seg * frames >= (1ll << 31) / (3 * V * V)) CSK_FAIL("agcn_embed_attention: too many skeletons for one launch");
-    if (!per_frame && !scratch) CSK_FAIL("agcn_embed_attention: the per-segment form needs n_seg * 3 * ceil(frames / 7) * V * V floats of scratch");
+    if (!per_frame && !scratch)
+        CSK_FAIL("agcn_embed_attention: the per-segment form needs n_seg * 3 * ceil(frames / (128 / V)) * V * V floats of scratch");
     EmbAttParams p;
     p.x = x; p.w = w_pairs; p.bias = b_pairs; p.a_sum = a_sum; p.ell_val = ell_val; p.part = scratch;
     p.x_seg_stride = x_seg_stride; p.x_chan_stride = x_chan_stride;
     p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD); p.Mpad = round_up(6 * inter, CSK_MT); p.frames = frames;
-    p.qtiles = (frames + 6) / 7;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (per_frame) {
-        if (inter == 16) return launch_embed_attention<16, 3, false>(p, n_seg, s);
-        if (inter == 32) return launch_embed_attention<32, 1, false>(p, n_seg, s);
-        return launch_embed_attention<64, 1, false>(p, n_seg, s);
-    }
-    if (inter == 16) rc = launch_embed_attention<16, 3, true>(p, n_seg, s);
-    else if (inter == 32) rc = launch_embed_attention<32, 1, true>(p, n_seg, s);
-    else rc = launch_embed_attention<64, 1, true>(p, n_seg, s);
+#define CSK_EA_LAUNCH(VV, CL)                                                                            \
+    (inter == 16 ? launch_embed_attention<16, 3, VV, CL>(p, n_seg, s)                                    \
+                 : inter == 32 ? launch_embed_attention<32, 1, VV, CL>(p, n_seg, s) : launch_embed_attention<64, 1, VV, CL>(p, n_seg, s))
+    if (per_frame) return V == 18 ? CSK_EA_LAUNCH(18, false) : CSK_EA_LAUNCH(25, false);
+    rc = V == 18 ? CSK_EA_LAUNCH(18, true) : CSK_EA_LAUNCH(25, true);
+#undef CSK_EA_LAUNCH
     if (rc) return rc;
-    hipLaunchKernelGGL(agcn_softmax_parts_kernel, dim3(3 * n_seg), dim3(NTHREADS), 0, s, scratch, a_sum, ell_val, (int)p.qtiles,
+    const int nparts = (frames + 128 / V - 1) / (128 / V);
+    hipLaunchKernelGGL(agcn_softmax_parts_kernel, dim3(3 * n_seg), dim3(NTHREADS), 0, s, scratch, a_sum, ell_val, nparts,
                        inter * frames, V);
     return (int)hipGetLastError();
 }

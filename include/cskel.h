@@ -190,14 +190,14 @@ int csk_agcn_attention_f32(const float *E, const float *a_sum, float *ell_val, f
                            void *stream);
 
 /* The two entries above fused (no E tensor in memory): the six embedding 1x1 convs and the attention.
- * x: n_seg segments of `frames` frames (element (seg, c, frame, v) at seg*x_seg_stride + c*x_chan_stride + frame*V + v, rows
- * 8-byte aligned); w_pairs / b_pairs: the embedding weights packed as for csk_conv1x1_f32 ([C_in_pad][C_out_pad], C_out =
+ * x: n_seg segments of `frames` frames (element (seg, c, frame, v) at seg*x_seg_stride + c*x_chan_stride + frame*V + v); w_pairs / b_pairs: the embedding weights packed as for csk_conv1x1_f32 ([C_in_pad][C_out_pad], C_out =
  * 6*inter) but in PAIR-MAJOR row order: rows i*2*inter + k = a_conv_i[k], i*2*inter + inter + k = b_conv_i[k].
  * per_frame = 1 (CoAGCN step form, models/coa_gcn/coa_gcn.py:11-14: the module applied per frame, T = 1; a segment is a
  *   channel-major slot, its "frames" are skeletons): one attention per (segment, frame), ell_val[(seg*frames + frame)][i][w][v].
  * per_frame = 0 (A-GCN clip form, models/a_gcn/a_gcn.py:53-63): one attention per segment over all frames, ell_val[seg][i][w][v];
- *   scratch: n_seg * 3 * ceil(frames / 7) * V * V floats (partial logits per tile of 7 frames, summed in tile order).
- * Built for V = 18 and inter in {16, 32, 64}; fails otherwise (callers then use the two entries above). */
+ *   scratch: n_seg * 3 * ceil(frames / (128 / V)) * V * V floats (partial logits per tile of 128 / V frames, summed in tile order).
+ * Built for V in {18, 25} and inter in {16, 32, 64}; fails otherwise (callers then use the two entries above).  Even V: rows
+ * 8-byte aligned. */
 int csk_agcn_embed_attention_f32(const float *x, const float *w_pairs, const float *b_pairs, const float *a_sum, float *ell_val,
                                  float *scratch, int n_seg, int c_in, int inter, int frames, int V, int per_frame,
                                  int64_t x_seg_stride, int64_t x_chan_stride, void *stream);

@@ -58,6 +58,33 @@ def test_adaptive_graph_conv_vs_oracle(ci, co, t, v):
     check_parity(got, want, shape=(ci, co, t, v))
 
 
+@pytest.mark.parametrize("v,t", [(25, 23), (18, 30)])
+def test_fused_attention_entry_clip_form_equals_two_launch_route(v, t):
+    """csk_agcn_embed_attention_f32, per-segment form, called directly (the module uses it at V = 18 only: at V = 25 it measured
+    slower than the two launches) against csk_conv1x1_f32 + csk_agcn_attention_f32 on the same operands: the adjacencies agree
+    to fp32 summation-order level."""
+    from continual_skeletons_amd import native
+    A = A_KIN if v == 18 else pkg.ntu_graph().A
+    ci, co, n = 64, 128, 3
+    m = pkg.AdaptiveGraphConvolution(ci, co, A).eval()
+    _randomise(m, 31)
+    m = m.to(DEV)
+    ops = m._packed_ops(torch.device(DEV))
+    x = torch.rand(n, ci, t, v, generator=torch.Generator().manual_seed(8)).to(DEV)
+    inter, e_ch = m.inter_c, 6 * m.inter_c
+    E = torch.empty((n * e_ch * t * v + 4,), device=DEV)[: n * e_ch * t * v].view(n, e_ch, t, v)
+    native.check(native.lib().csk_conv1x1_f32(native.ptr(x), native.ptr(E), native.ptr(ops["w_embed"]), native.ptr(ops["b_embed"]), n, ci,
+                                              e_ch, t, v, ci * t * v, t * v, e_ch * t * v, t * v, native.stream_of(x)), "conv1x1")
+    want = m._attention(E, ops, n, t, v, e_ch * t * v, t * v)
+    got = torch.empty((n, 3, v, v), device=DEV)
+    ft = 128 // v
+    scratch = torch.empty((n, 3, (t + ft - 1) // ft, v, v), device=DEV)
+    native.check(native.lib().csk_agcn_embed_attention_f32(
+        native.ptr(x), native.ptr(ops["w_embed_pairs"]), native.ptr(ops["b_embed_pairs"]), native.ptr(ops["a_sum"]), native.ptr(got),
+        native.ptr(scratch), n, ci, inter, t, v, 0, ci * t * v, t * v, native.stream_of(x)), "embed_attention")
+    check_parity(got.cpu(), want.cpu(), tol=1e-5, shape=(ci, co, t, v))
+
+
 def test_adaptive_graph_conv_other_joint_counts():
     """A skeleton layout that is neither Kinetics nor NTU (V = 20, a random 3-subset adjacency): the dense kernels of gcn.hip
     (gcn_stage_dense_kernel for 128-row tiles, gcn_stage_kernel for 64-row ones) instead of gcn_dense.hip."""
@@ -98,17 +125,18 @@ def test_agcn_block_clip_and_continual(graph, c):
                 check_parity(g.cpu(), w, note=t)
 
 
-@pytest.mark.parametrize("native_plan", [True, False])
-def test_coagcn_model_steps_vs_oracle(native_plan):
+@pytest.mark.parametrize("native_plan,graph", [(True, "kinetics"), (False, "kinetics"), (True, "ntu")])
+def test_coagcn_model_steps_vs_oracle(native_plan, graph):
     """The whole CoAGCN stack stepping against the oracle: through the native step executor (csk_co_plan with the adaptive
     graph-conv operands) and with every launch driven from Python -- the two must also agree bit for bit."""
-    A = A_KIN
-    net = pkg.CoAGcn(A, input_shape=(3, 300, 18, 2), num_classes=400, pool_size=4, pool_padding=1).eval()
+    A = A_KIN if graph == "kinetics" else pkg.ntu_graph().A
+    V = A.shape[-1]
+    net = pkg.CoAGcn(A, input_shape=(3, 300, V, 2), num_classes=400 if V == 18 else 60, pool_size=4, pool_padding=1).eval()
     net.use_native_plan = native_plan
-    randomise_unit_(net, 11, attn_scale=1 / 18)         # O(1) activations through all ten blocks
+    randomise_unit_(net, 11, attn_scale=1 / V)          # O(1) activations through all ten blocks
     net_sd = net.state_dict()
     sd = {k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in net_sd.items()}
-    x = torch.rand(1, 3, 96, 18, 2, generator=torch.Generator().manual_seed(4))
+    x = torch.rand(1, 3, 96, V, 2, generator=torch.Generator().manual_seed(4))
     orc = o.CoStGcnOracle(sd, pool_size=4, pool_padding=1)
     for b in orc.blocks:
         b.gcn = o.adaptive_graph_conv

@@ -24,7 +24,9 @@ ap.add_argument("--warm-cycles", type=int, default=0, help="default: enough to f
 ap.add_argument("--no-fuse", action="store_true", help="two launches per block everywhere (no csk_co_block_step_f32)")
 ap.add_argument("--force-ksplit", type=int, default=0, help="split-K factor forced on blocks with C_out >= --ksplit-min-c (experiment)")
 ap.add_argument("--ksplit-min-c", type=int, default=256)
-ap.add_argument("--model", default="costgcn", choices=["costgcn", "coagcn"], help="coagcn: BASELINE configs[3], Kinetics-400 shape (V = 18)")
+ap.add_argument("--no-fuse-attention", action="store_true", help="A-GCN: embedding conv and attention as two launches (Python engine)")
+ap.add_argument("--model", default="costgcn", choices=["costgcn", "coagcn", "coagcn_ntu"],
+                help="coagcn: BASELINE configs[3], Kinetics-400 shape (V = 18); coagcn_ntu: the same model on the NTU-60 shape (V = 25)")
 args = ap.parse_args()
 
 pkg = _bootstrap.load()
@@ -40,6 +42,9 @@ def make():
     if args.model == "coagcn":
         net = pkg.CoAGcn(pkg.kinetics_graph().A, bench.KIN_SHAPE, 400).eval()
         bench.randomise_(net, seed=0, attn_scale=1 / 18)
+    elif args.model == "coagcn_ntu":
+        net = pkg.CoAGcn(pkg.ntu_graph().A, (3, 300, 25, 2), 60).eval()
+        bench.randomise_(net, seed=0, attn_scale=1 / 25)
     else:
         net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
         bench.randomise_(net, seed=0)
@@ -50,6 +55,9 @@ def make():
     if args.no_fuse:
         for blk in net.layers.values():
             blk.fuse_step = False
+    if args.no_fuse_attention:
+        for blk in net.layers.values():
+            blk.gcn.fuse_embed_attention = False
     return net.to(dev)
 
 
