@@ -336,3 +336,40 @@ def test_gcn_bf16x3_entry_validates_arguments_without_a_gpu():
     assert call(cnt_=(C.c_int32 * 3)(2, 1, 4)) == -1 and b"skeleton-sparse" in lib.csk_last_error()
     assert call(c_in=64) == -1 and b"identity residual" in lib.csk_last_error()
     assert call(c_in=64, res=2) == -1 and b"conv residual without" in lib.csk_last_error()
+
+
+def test_fused_attention_entry_and_plan_validate_their_arguments_without_a_gpu():
+    """csk_agcn_embed_attention_f32 (shapes it is built for, alignment, scratch of the per-segment form) and the adaptive
+    graph-conv fields of csk_co_layer (csk_co_plan_create) are checked before anything is launched."""
+    import ctypes as C
+    lib = pkg.native.lib()
+    fake = C.c_void_p(0x1000)
+
+    def call(x=fake, scratch=None, inter=16, V=18, per_frame=1, seg_stride=1000, chan_stride=100):
+        return lib.csk_agcn_embed_attention_f32(x, fake, fake, fake, fake, scratch, 2, 64, inter, 4, V, per_frame, seg_stride, chan_stride, None)
+    assert call(x=None) == -1 and b"null pointer" in lib.csk_last_error()
+    assert call(V=20) == -1 and b"built for V in {18, 25}" in lib.csk_last_error()
+    assert call(inter=24) == -1 and b"inter in {16, 32, 64}" in lib.csk_last_error()
+    assert call(x=C.c_void_p(0x1004)) == -1 and b"8-byte aligned" in lib.csk_last_error()
+    assert call(chan_stride=101) == -1 and b"8-byte aligned" in lib.csk_last_error()
+    assert call(per_frame=0) == -1 and b"scratch" in lib.csk_last_error()
+    # plan: an adaptive layer needs all four agcn_* operands and the dense ELL pattern (ell_w = V, ell_cnt = {V, V, V})
+    L = (pkg.native.CoLayer * 1)()
+    l = L[0]
+    l.c_in, l.c_out, l.stride, l.res_kind, l.gcn_res_mode, l.ell_w, l.tcn_ksplit = 3, 64, 1, 0, 2, 18, 1
+    for j in range(3):
+        l.ell_cnt[j] = 18
+    for f in ("gcn_w", "gcn_bias", "ell_src", "tcn_w", "tcn_bias", "y_ring", "out_ring"):
+        setattr(l, f, 0x1000)
+    l.agcn_inter, l.agcn_w_pairs, l.agcn_b_pairs, l.agcn_a_sum = 16, 0x1000, 0x1000, 0x1000      # agcn_adj missing
+    lib.csk_co_plan_create.restype = C.c_void_p
+    plan = lib.csk_co_plan_create(1, C.byref(L), fake, 2, 3, 18, 2, 72, fake, fake, 400, fake, fake, 4, 1, fake, fake)
+    assert not plan and b"adaptive graph conv" in lib.csk_last_error()
+    l.agcn_adj = 0x1000
+    l.ell_w = 6                                          # not the dense pattern
+    plan = lib.csk_co_plan_create(1, C.byref(L), fake, 2, 3, 18, 2, 72, fake, fake, 400, fake, fake, 4, 1, fake, fake)
+    assert not plan and b"adaptive graph conv" in lib.csk_last_error()
+    l.ell_w = 18
+    plan = lib.csk_co_plan_create(1, C.byref(L), fake, 2, 3, 18, 2, 72, fake, fake, 400, fake, fake, 4, 1, fake, fake)
+    assert plan
+    lib.csk_co_plan_destroy(C.c_void_p(plan))
