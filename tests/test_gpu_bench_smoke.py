@@ -48,4 +48,6 @@ def test_bench_line_contract(workload):
             assert k[leg]["value"] > 0 and k[leg]["unit"] == unit
             assert k[leg]["roofline_config"]["bound"] == "mfma" and 0 < k[leg]["roofline_config"]["frac"] < 1
             assert k[leg]["cpu_baseline"]["kind"] == "port" and k[leg]["cpu_baseline"]["value"] > 0
+        b3 = k["agcn_clip"]["bf16x3"]                     # opt-in mode of the A-GCN clip leg: its own key
+        assert b3["value"] > 0 and "bf16x3" in b3["dtype"] and b3["max_abs_logit_diff_vs_f32"] < 1e-4
         assert d["costgcn_online"]["roofline_config"]["frac"] > 0
