@@ -478,6 +478,83 @@ template <int OCC, bool BGLDS = false> double run_glds(int chunks, int blocks, s
     return flops / (ms * 1e-3) / 1e12;
 }
 
+
+// STRUCT8: the level-3 structure with EIGHT waves on a 128 x 256 tile (one workgroup per CU, two waves per SIMD from the SAME
+// workgroup): a staged weight vector feeds twice the MFMAs (4.5 f32x4 of W + 18 dwords of B per thread and chunk).
+template <int LEVEL>
+__global__ __launch_bounds__(512, 1) void struct8_kernel(float *out, const float *gw, const float *gb, int chunks) {
+    constexpr int L8 = 504;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem, *Bl = smem + TAPS * KC * MT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < TAPS * KC * MT + KC * L8; i += 512) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
+    __syncthreads();
+    const int offA = (wave & 1) * 64 + l31, off0 = (wave >> 1) * 64 + l31, off1 = off0 + 32;
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    constexpr int NW = 5, NB = 8;                          // 4.5 f32x4 of W; B: 8 rows x 504 floats = 1008 f32x4 / 512 = 2 f32x4 ... as 8 dwords
+    f32x4 wv[NW];
+    float bv[NB];
+    const int wlim = TAPS * KC * MT / 4;
+    for (int u = 0; u < NW; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(gw + (u * 512 + tid) * 4);
+    for (int u = 0; u < NB; ++u) bv[u] = gb[(size_t)blockIdx.x * 65536 + u * 512 + tid];
+    for (int c = 0; c < chunks; ++c) {
+        if (LEVEL >= 1) __syncthreads();
+        if (LEVEL >= 2) {
+#pragma unroll
+            for (int u = 0; u < NW; ++u)
+                if (u * 512 + tid < wlim) *reinterpret_cast<f32x4 *>(Wl + (u * 512 + tid) * 4) = wv[u];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) Bl[u * L8 + (tid % 504)] = bv[u] + (float)(tid >> 8);
+        }
+        if (LEVEL >= 1) __syncthreads();
+        const float *gwc = gw + (size_t)((c + 1) & 31) * 9216, *gbc = gb + (size_t)blockIdx.x * 65536 + (size_t)((c + 1) & 7) * 4608;
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3) {
+            if (LEVEL >= 3) {
+#pragma unroll
+                for (int u = g3; u < NW; u += 3) wv[u] = *reinterpret_cast<const f32x4 *>(gwc + (u * 512 + tid) * 4);
+#pragma unroll
+                for (int u = g3; u < NB; u += 3) bv[u] = gbc[u * 512 + tid];
+            }
+            for (int r = 3 * g3; r < 3 * g3 + 3; ++r) {
+                const float *wr = Wl + r * (KC * MT) + offA + kh * MT, *br = Bl + r * 25 + kh * L8;
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    const float a0 = wr[2*s*MT], a1 = wr[2*s*MT+32], b0 = br[2*s*L8+off0], b1 = br[2*s*L8+off1];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) s += acc[a][b][g];
+    for (int u = 0; u < NW; ++u) s += wv[u][0];
+    for (int u = 0; u < NB; ++u) s += bv[u];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int L> double run_struct8(int chunks, int blocks) {
+    float *out, *gw, *gb;
+    hipMalloc(&out, (size_t)blocks * 512 * 4);
+    hipMalloc(&gw, (size_t)34 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)34 * 9216 * 4 + 65536);
+    hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
+    const size_t lds = (size_t)(TAPS * KC * MT + KC * 504) * 4 + 32 * 1024;      // > 80 KB: one workgroup per CU
+    hipFuncSetAttribute((const void *)struct8_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((struct8_kernel<L>), dim3(blocks), dim3(512), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((struct8_kernel<L>), dim3(blocks), dim3(512), lds, 0, out, gw, gb, chunks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    hipFree(out); hipFree(gw); hipFree(gb);
+    const double flops = (double)blocks * 8 * chunks * TAPS * (KC / 2) * 4 * 4096.0;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
 template <int L, int OCC = 2> double run_struct(int chunks, int blocks, size_t lds_extra = 0) {
     float *out, *gw, *gb;
     hipMalloc(&out, (size_t)blocks * 256 * 4);
@@ -539,6 +616,8 @@ int main() {
     printf("glds W stages, 2 workgroups/CU:                         %.1f TFLOP/s\n", run_glds<2>(chunks, blocks, 20 * 1024));
     printf("glds W stages, 3 workgroups/CU:                         %.1f TFLOP/s\n", run_glds<3>(chunks, 768 * 4));
     printf("glds W stages + glds activation tile, 2 / 3 workgroups/CU: %.1f / %.1f TFLOP/s\n", run_glds<2, true>(chunks, blocks, 20 * 1024), run_glds<3, true>(chunks, 768 * 4));
+    printf("8 waves, 128 x 256 tile, 1 workgroup/CU: struct 0 / 1 / 2 / 3: %.1f / %.1f / %.1f / %.1f TFLOP/s\n", run_struct8<0>(chunks, 256 * 6),
+           run_struct8<1>(chunks, 256 * 6), run_struct8<2>(chunks, 256 * 6), run_struct8<3>(chunks, 256 * 6));
     printf("glds W stages, 1 workgroup/CU:                          %.1f TFLOP/s\n", run_glds<2>(chunks, 256 * 6, 64 * 1024));
     return 0;
 }
