@@ -354,6 +354,37 @@ def load_traffic(name="traffic_tcn_stage.json"):
     return None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: this process becomes the parent of N fresh rank
+    processes (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, one rank per
+    GPU, rendezvous on 127.0.0.1), relays rank 0's single JSON line on stdout (anything else the ranks print goes to
+    stderr) and returns the launcher's exit code.  The parent makes NO GPU call -- no torch.cuda.*, no _bootstrap.load(), no
+    process group -- before or after starting its children, and it never re-executes itself: it only spawns and exits."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for ln in proc.stdout:
+        if ln.startswith("{") and lines == 0:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write(f"bench.py: the {n} ranks exited 0 but printed {lines} JSON lines\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,12 +410,13 @@ def main():
     ap.add_argument("--cpu-budget-config4", type=float, default=14.0, help="seconds of CPU work for the two configs[3] cpu_baseline legs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))            # parent: starts the ranks, relays rank 0's line, never touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started as one rank of a WORLD_SIZE={world} job: the two must agree")
     import torch.distributed as dist
     # CSK_BENCH_BACKEND=gloo (debugging aid): lets several ranks share one GPU, which RCCL refuses -- used to exercise the
     # N > 1 code path of this script on a 1-GPU box; real runs use the default, "nccl" = RCCL, one rank per GPU

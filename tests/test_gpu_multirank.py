@@ -114,6 +114,25 @@ def test_bench_two_ranks_toy_sizes():
     assert "agcn_kinetics" not in d          # the config-4 side numbers are per GPU, reported at N = 1 only
 
 
+def test_bench_self_launch_two_ranks_toy_sizes():
+    """`python bench.py --gpus 2` WITHOUT a launcher: the parent (no GPU call of its own) starts the two ranks itself and relays
+    rank 0's line -- the form the driver's scaling run uses (`python3 bench.py --gpus N ...`)."""
+    env = dict(os.environ, CSK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "4", "--streams", "6", "--steps", "2",
+           "--warmup", "1", "--step-cycles", "2", "--stream-shards", "2", "--no-cpu-baseline", "--config5-batch", "3",
+           "--no-split-leg"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]          # ONE line on stdout, nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert d["config5"]["clips_per_gpu"] == 3 and d["config5"]["global_batch"] == 6 and d["config5"]["value"] > 0
+    assert d["ranks_seen"] == 1 and d["collective_backend"] == "gloo" and d["value"] > 0
+
+
 RCCL_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["CSK_ROOT"])

@@ -57,3 +57,23 @@ def test_all_gather_even_world2():
 
 def test_all_gather_ragged_world2():
     _run(7)
+
+
+def test_bench_self_launches_its_ranks_without_a_gpu_call_in_the_parent():
+    """`python bench.py --gpus 2` (no launcher, no RANK in the environment): the parent must start the rank processes
+    itself instead of exiting with a usage message.  On this CPU box the ranks then fail for lack of a GPU -- what is
+    checked is that they were started by torch.distributed.run, that the parent relayed their failure as a non-zero exit
+    code and that it printed nothing on stdout (no half-made JSON line)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--batch", "2"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode == 0:                      # a box with >= 2 GPUs: the line must be the 2-rank one
+        import json
+        assert json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+        return
+    assert "launch multi-GPU runs with" not in out.stderr
+    assert "local_rank: 0" in out.stderr or "ChildFailedError" in out.stderr, out.stderr[-1500:]
+    assert out.stdout.strip() == ""
