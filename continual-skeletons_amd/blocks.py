@@ -86,23 +86,17 @@ def set_precision(module: nn.Module, precision: str = "f32") -> nn.Module:
     exact fp32; the 64-channel layers and A-GCN's adaptive graph conv keep the exact kernels)."""
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
-    hit = 0
-    for m in module.modules():
-        if isinstance(m, SpatioTemporalBlock):
-            if precision != "f32" and not (m._native_tail and m.tcn.kernel_size == 9):
-                raise NotImplementedError("bf16x3 is built for blocks with the native 9 x 1 temporal conv")
-            m.precision = precision
-            m.refold()
-            hit += 1
-        elif type(m) is GraphConvolution:
-            m.precision = precision
-            m.refold()
-    if not hit:
+    blocks_ = [m for m in module.modules() if isinstance(m, SpatioTemporalBlock)]
+    if not blocks_:
         raise ValueError("no SpatioTemporalBlock below this module: nothing to set")
+    # validate EVERY block before touching any: a refusal must not leave a half-switched (mixed-precision) model behind
+    for m in blocks_:
+        if precision != "f32" and not (m._native_tail and m.tcn.kernel_size == 9):
+            raise NotImplementedError("bf16x3 is built for blocks with the native 9 x 1 temporal conv; the model is unchanged")
     for m in module.modules():
-        hook = getattr(m, "_precision_changed", None)
-        if hook is not None:
-            hook()
+        if isinstance(m, SpatioTemporalBlock) or type(m) is GraphConvolution:
+            m.precision = precision
+            m.refold()
     return module
 
 

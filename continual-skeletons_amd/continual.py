@@ -13,9 +13,9 @@ Protocol (anchored on the reference's tests, see oracle/stgcn_oracle.py:CoBlockO
   * the emission of step s equals the clip block's output at t = (s - delay) / S;
   * ``forward_steps(x, pad_end)``: all frames, optionally flushed with ``padding`` zero post-GCN frames;
   * ``clean_state()`` zeroes the window (zero state == the clip conv's left zero padding).
-State layout (channel-major, see include/cskel.h): per block a y ring [16][C_out][P] and an output ring
-[16][C_out][P]; the output ring of block l is the input/residual history of block l+1, so the
-residual FIFO (``co.Delay``) costs no copy.  ``engine_advance`` consumes up to 8 frames per call (4 = one
+State layout (channel-major, see include/cskel.h): per block a y ring [8 + max_in][C_out][P] and an output ring
+[4 + max_in of the next block][C_out][P] (max_in = frames one launch can receive = 8 / cumulative stride); the output
+ring of block l is the input/residual history of block l+1, so the residual FIFO (``co.Delay``) costs no copy.  ``engine_advance`` consumes up to 8 frames per call (4 = one
 stride cycle of the 10-block stack) with one GCN launch and one multi-emission TCN launch per block,
 which is what fills the GPU at ~1000 streams; per-frame stepping is the same code with r = 1.
 """
@@ -31,9 +31,19 @@ from . import blocks, fold, native
 from .blocks import GraphConvolution, SpatioTemporalBlock, TemporalConvolution, _Folded, init_weights, unity, zero
 from .models import layer_table
 
-HIST = 16    # depth of an input / output history ring (>= residual lag 4 + the frames of the longest cycle)
-YRING = 16   # depth of the post-GCN ring: k-1 = 8 window frames + up to 8 new frames per launch
 MAX_CYCLE = 8
+
+
+def y_slots(max_in: int) -> int:
+    """Depth of a post-GCN ring: the k-1 = 8 window frames of co.Conv2d + the frames one launch can receive
+    (include/cskel.h: CSK_CO_Y_SLOTS)."""
+    return 8 + max_in
+
+
+def in_slots(max_in: int) -> int:
+    """Depth of an input / output history ring: residual lag (k-1)/2 = 4 (co.Delay) + the frames one launch of the
+    CONSUMING block can receive (include/cskel.h: CSK_CO_IN_SLOTS)."""
+    return 4 + max_in
 
 
 def _round4(n: int) -> int:
@@ -120,7 +130,8 @@ class CoTemporalConvolution(TemporalConvolution):
 class _BlockState:
     """Slice of the state slab owned by one block: y ring, output ring, (optionally own) input ring, counters."""
 
-    def __init__(self, c_in, c_out, k, p, device, xin=None, ksplit=1, max_emit=MAX_CYCLE, scratch=None):
+    def __init__(self, c_in, c_out, k, p, device, xin=None, ksplit=1, max_emit=MAX_CYCLE, scratch=None, max_in=MAX_CYCLE,
+                 out_slots=None):
         self.p = p
         self.ksplit = ksplit
         # split-K scratch of the TCN step: raw partial sums of the emissions ONE launch can produce (max_emit: MAX_CYCLE
@@ -137,10 +148,15 @@ class _BlockState:
             self.partial = scratch[:need].view(max_emit * ksplit, c_out, p)
         else:
             self.partial = torch.empty((max_emit * ksplit, c_out, p), device=device, dtype=torch.float32)
-        self.y = torch.zeros((YRING, c_out, p), device=device, dtype=torch.float32)
-        self.out = torch.zeros((HIST, c_out, p), device=device, dtype=torch.float32)
+        # ring depths from what ONE launch can receive / emit (y_slots / in_slots above); a stand-alone block keeps an
+        # output ring deep enough for max_emit emissions (and the 4 a fused cycle writes)
+        self.max_in = max_in
+        self.y = torch.zeros((y_slots(max_in), c_out, p), device=device, dtype=torch.float32)
+        self.out = torch.zeros((out_slots or max(4, max_emit), c_out, p), device=device, dtype=torch.float32)
         self.owns_xin = xin is None
-        self.xin = torch.zeros((HIST, c_in, p), device=device, dtype=torch.float32) if xin is None else xin
+        self.xin = torch.zeros((in_slots(max_in), c_in, p), device=device, dtype=torch.float32) if xin is None else xin
+        if self.xin.shape[0] < in_slots(max_in):
+            raise ValueError(f"input ring of {self.xin.shape[0]} slots is too shallow for launches of {max_in} frames")
         self.s = 0      # frames received
         self.e = 0      # frames emitted
 
@@ -226,11 +242,13 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
 
     # ---- persistent state --------------------------------------------------------------------------
     def bind_state(self, p: int, device, xin: Optional[torch.Tensor] = None, max_emit: int = MAX_CYCLE,
-                   scratch: Optional[torch.Tensor] = None) -> _BlockState:
-        """(Re)allocate this block's slab slice for P positions; ``xin`` = upstream block's output ring; ``max_emit`` =
-        emissions one launch of this block can produce; ``scratch`` = split-K scratch shared with the other blocks."""
+                   scratch: Optional[torch.Tensor] = None, max_in: int = MAX_CYCLE, out_slots: Optional[int] = None) -> _BlockState:
+        """(Re)allocate this block's slab slice for P positions; ``xin`` = upstream block's output ring; ``max_in`` /
+        ``max_emit`` = frames one launch of this block can receive / emit; ``out_slots`` = depth of the output ring (what
+        the consuming block needs as its input history); ``scratch`` = split-K scratch shared with the other blocks."""
         self._state = _BlockState(self.in_channels, self.out_channels, self.kernel_size, p, device, xin,
-                                  ksplit=self._pick_ksplit(p), max_emit=max_emit, scratch=scratch)
+                                  ksplit=self._pick_ksplit(p), max_emit=max_emit, scratch=scratch, max_in=max_in,
+                                  out_slots=out_slots)
         return self._state
 
     def scratch_floats(self, p: int, max_emit: int = MAX_CYCLE) -> int:
@@ -269,13 +287,14 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         ``(first_out_slot, n_emit)`` for the emissions of these frames, or None.  ``flush`` pushes zero
         post-GCN frames instead (end padding)."""
         st, k = self._state, self.kernel_size
+        HIST, YRING, OUT = st.xin.shape[0], st.y.shape[0], st.out.shape[0]      # ring depths of this block's slab slice
         if self.precision != "f32":
             raise NotImplementedError(
                 "precision 'bf16x3' covers the clip kernels only: in step mode every ring slot feeds ONE tap per emission, so "
                 "the split kernel would stage twice the bytes per MFMA of the clip form and is bound by staging, not by the "
                 "matrix pipe (priced in DESIGN.md); step with the default precision")
-        if not 1 <= r <= MAX_CYCLE:
-            raise ValueError(f"engine_advance handles 1..{MAX_CYCLE} frames per call, got {r}")
+        if not 1 <= r <= st.max_in:
+            raise ValueError(f"engine_advance handles 1..{st.max_in} frames per call of this block, got {r}")
         s0, p = st.s, st.p
         if not flush and self._fusable(r, s0, V):
             return self._fused_advance(n_frames, V)
@@ -299,7 +318,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         ops = self._packed_ops(st.y.device)
         lag = (k - 1) // 2              # emission s pairs with input frame s - 4 (co.Delay / residual_shrink)
         mode = {"none": 0, "identity": 1, "conv": 2}[self.kind]
-        slot0 = st.e % HIST
+        slot0 = st.e % OUT
         # one launch; with split-K at most max_emit emissions per launch (the scratch holds that many partial sums) --
         # only the end-padding flush of a stack exceeds it (per-output summation order does not depend on the grouping)
         group = n_emit if st.partial is None else min(n_emit, st.max_emit)
@@ -308,7 +327,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             blocks.tcn_step_launch(
                 native.ptr(st.y), YRING, f0 % YRING, self.stride, ne, native.ptr(ops["w"]),
                 native.ptr(st.xin) if mode else None, HIST, (f0 - lag) % HIST, self.stride,
-                native.ptr(ops["w_res"]), native.ptr(ops["bias"]), native.ptr(st.out), HIST, (slot0 + e0) % HIST,
+                native.ptr(ops["w_res"]), native.ptr(ops["bias"]), native.ptr(st.out), OUT, (slot0 + e0) % OUT,
                 self.out_channels, self.out_channels, p, k, mode, self.in_channels if mode else 0, 1,
                 st.ksplit, native.ptr(st.partial) if st.partial is not None else None, native.stream_of(st.y))
         st.e += n_emit
@@ -328,13 +347,14 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
 
     def _fused_advance(self, n_skel: int, V: int):
         st = self._state
+        HIST, YRING, OUT = st.xin.shape[0], st.y.shape[0], st.out.shape[0]
         g, t = self.gcn._packed_ops(st.y.device), self._packed_ops(st.y.device)
-        s0, slot0 = st.s, st.e % HIST
+        s0, slot0 = st.s, st.e % OUT
         rc = native.lib().csk_co_block_step_f32(
             native.ptr(st.xin), HIST, s0 % HIST, self.in_channels, native.ptr(g["w"]), native.ptr(g["bias"]),
             native.ptr(g["ell_src"]), native.ptr(g["ell_val"]), native.ptr(g["ell_cnt_host"]), g["ell_w"], g["res_mode"],
             native.ptr(st.y), YRING, s0 % YRING, native.ptr(t["w"]), native.ptr(t["bias"]),
-            {"none": 0, "identity": 1}[self.kind], (s0 - (self.kernel_size - 1) // 2) % HIST, native.ptr(st.out), HIST, slot0,
+            {"none": 0, "identity": 1}[self.kind], (s0 - (self.kernel_size - 1) // 2) % HIST, native.ptr(st.out), OUT, slot0,
             self.out_channels, n_skel, V, st.p, native.stream_of(st.y))
         native.check(rc, "csk_co_block_step_f32")
         st.s += 4
@@ -346,6 +366,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         ``CoGraphConv``, models/base.py:390-400): applied per frame as ``module(x_t.unsqueeze(2)).squeeze(2)``
         (base.py:273-276) on (NM, C, 1, V) tensors converted from / to the channel-major ring slots."""
         q = n_frames * V
+        HIST, YRING = st.xin.shape[0], st.y.shape[0]
         for j in range(run):
             xs, ys = st.xin[(s + j) % HIST], st.y[(s + j) % YRING]
             x_t = xs[:, :q].reshape(self.in_channels, n_frames, V).permute(1, 0, 2).unsqueeze(2).contiguous()
@@ -375,7 +396,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             raise RuntimeError(f"expected (N, {self.in_channels}, V) frame, got {tuple(x_t.shape)}")
         st = self._ensure_state(n, v, x_t.device)
         keep = (st.s, st.e)
-        st.xin[st.s % HIST, :, : n * v] = x_t.permute(1, 0, 2).reshape(c, n * v)
+        st.xin[st.s % st.xin.shape[0], :, : n * v] = x_t.permute(1, 0, 2).reshape(c, n * v)
         slot = self.engine_step(n, v)
         if not update_state:       # one step only touches ring slots that are older than every window: counters suffice
             st.s, st.e = keep
@@ -477,18 +498,22 @@ class CoStGcn(_Folded):
     def _bind(self, n, device):
         c_in, _, v, m = self.input_shape
         p = _round4(n * m * v)
-        xin = torch.zeros((HIST, c_in, p), device=device, dtype=torch.float32)
+        xin = torch.zeros((in_slots(MAX_CYCLE), c_in, p), device=device, dtype=torch.float32)
         self._xin0, self._p, self._n = xin, p, n
-        # emissions one launch of block i can produce: MAX_CYCLE input frames / cumulative temporal stride; the split-K
-        # scratch is ONE buffer sized by its largest user (launches of a model are stream-ordered)
-        emits, cum = [], 1
+        # frames one launch of block i can receive / emit: MAX_CYCLE input frames / cumulative temporal stride.  They size
+        # the rings (y: 8 + max_in, output = next block's input history: 4 + its max_in) and the split-K scratch, which is
+        # ONE buffer sized by its largest user (launches of a model are stream-ordered)
+        recv, emits, cum = [], [], 1
         for i in range(10):
+            recv.append(max(1, MAX_CYCLE // cum))
             cum *= self.layers[f"layer{i + 1}"].stride
             emits.append(max(1, MAX_CYCLE // cum))
         need = max(self.layers[f"layer{i + 1}"].scratch_floats(p, emits[i]) for i in range(10))
         self._scratch = torch.empty((need,), device=device, dtype=torch.float32) if need else None
         for i in range(10):
-            st = self.layers[f"layer{i + 1}"].bind_state(p, device, xin, max_emit=emits[i], scratch=self._scratch)
+            out_slots = in_slots(recv[i + 1]) if i < 9 else max(4, emits[i])
+            st = self.layers[f"layer{i + 1}"].bind_state(p, device, xin, max_emit=emits[i], scratch=self._scratch,
+                                                         max_in=recv[i], out_slots=out_slots)
             xin = st.out
         self._pool_ring = torch.zeros((self.pool_size, n, 256), device=device, dtype=torch.float32)
         self._pooled = torch.empty((n, 256), device=device, dtype=torch.float32)
@@ -509,19 +534,12 @@ class CoStGcn(_Folded):
         self._n = None
 
     # ---- native executor ---------------------------------------------------------------------------
-    def _weights_version(self):
-        """Identity + version of every parameter / buffer AS THEY ARE NOW (not as captured at bind time): an in-place
-        edit bumps _version, load_state_dict(assign=True) or swapping a sub-module changes id / data_ptr."""
-        return tuple((id(t), t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
-
-    _VERIFY_PER_CYCLE = 24      # tensors re-checked per cycle by the rotating window of _weights_changed
-
     def _mark_weights_dirty(self, *args, **kwargs):
         self.__dict__["_weights_dirty"] = True
 
     def _install_dirty_hooks(self):
         """load_state_dict on the model or ANY sub-module and .to() / .float() / ... (``_apply``) flag the plan's operands
-        as stale immediately; see _weights_changed for in-place edits."""
+        as stale immediately; see _weights_changed for everything else."""
         if self.__dict__.get("_dirty_hooks"):
             return
         for m in self.modules():
@@ -532,24 +550,36 @@ class CoStGcn(_Folded):
         self._mark_weights_dirty()
         return super()._apply(fn, *args, **kwargs)
 
+    def _weight_slots(self):
+        """Flat snapshot of where every parameter / buffer / sub-module of the model LIVES (owning ``_parameters`` /
+        ``_buffers`` / ``_modules`` dict + name) with the tensor's identity, storage pointer and version counter at the
+        time the native plan's operands were folded.  Walking the module tree costs ~0.65 ms per call; re-reading these
+        ~240 + ~140 dict slots costs ~0.06 ms, so _weights_changed can afford to be exact on every cycle."""
+        tensors, modules = [], []
+        for m in self.modules():
+            for d in (m._parameters, m._buffers):
+                for name, t in d.items():
+                    tensors.append((d, name, t, None if t is None else t.data_ptr(), None if t is None else t._version))
+            for name, child in m._modules.items():
+                modules.append((m._modules, name, child, len(m._modules)))
+        return tensors, modules
+
     def _weights_changed(self) -> bool:
-        """Hot-path staleness check of the native plan (one call per cycle; the full walk of ~240 tensors costs ~0.4 ms of
-        host time, which in latency mode is a whole GPU cycle).  Exact and immediate for load_state_dict / .to() (dirty
-        flag set by hooks) and for a swapped sub-module or parameter count (cheap structural check); in-place edits of
-        single tensors (``p.data.mul_(..)``) are found by a rotating window that re-reads data_ptr / _version of
-        _VERIFY_PER_CYCLE cached tensors per cycle, i.e. within len(tensors) / _VERIFY_PER_CYCLE (~10) cycles -- call
-        ``refold()`` after such an edit to apply it at once."""
+        """Staleness check of the native plan's operands, once per cycle, EXACT and immediate for every way the weights
+        can change: load_state_dict / .to() (dirty flag set by hooks), a replaced Parameter or buffer
+        (``net.fc.weight = nn.Parameter(..)``: the slot holds another object), a swapped, added or removed sub-module
+        (``net.layers.layer3.tcn.bn = ...``: the ``_modules`` slot holds another object / the dict changed size), an
+        in-place edit (``p.add_(..)``: version counter) and ``p.data = ...`` (storage pointer)."""
         if self.__dict__.pop("_weights_dirty", False):
             return True
-        keep = self._plan_keep
-        ts, ver = keep[2], keep[1]
-        n = len(ts)
-        i0 = self.__dict__.get("_verify_pos", 0)
-        for j in range(i0, min(i0 + self._VERIFY_PER_CYCLE, n)):
-            t = ts[j]
-            if (id(t), t.data_ptr(), t._version) != ver[j]:
+        tensors, modules = self._plan_keep[1]
+        for d, name, t, ptr, ver in tensors:
+            cur = d.get(name)
+            if cur is not t or (t is not None and (cur._version != ver or cur.data_ptr() != ptr)):
                 return True
-        self.__dict__["_verify_pos"] = 0 if i0 + self._VERIFY_PER_CYCLE >= n else i0 + self._VERIFY_PER_CYCLE
+        for d, name, child, size in modules:
+            if d.get(name) is not child or len(d) != size:
+                return True
         return False
 
     def refold(self):
@@ -576,15 +606,17 @@ class CoStGcn(_Folded):
             L.tcn_w_res = t["w_res"].data_ptr() if t["w_res"] is not None else None
             L.y_ring, L.out_ring = st.y.data_ptr(), st.out.data_ptr()
             L.tcn_ksplit = st.ksplit
+            L.y_slots, L.out_slots = st.y.shape[0], st.out.shape[0]
+            L.partial_emits = st.max_emit if st.partial is not None else 0
             L.tcn_partial = st.partial.data_ptr() if st.partial is not None else None
-            L.agcn_inter = 0
+            L.agcn_inter = L.agcn_adj_frames = 0
             if type(blk.gcn) is not GraphConvolution:      # adaptive graph conv: adjacency per skeleton frame (agcn.py)
                 a = blk.gcn.plan_operands(device)
                 adj = self.__dict__.get("_agcn_adj")
                 need = MAX_CYCLE * self._n * self.input_shape[3] * 3 * self.input_shape[2] ** 2      # [cycle frames][skeletons][3][V][V]
                 if adj is None or adj.numel() < need or adj.device != st.y.device:
                     adj = self.__dict__["_agcn_adj"] = torch.empty((need,), device=st.y.device, dtype=torch.float32)
-                L.agcn_inter = a["inter"]
+                L.agcn_inter, L.agcn_adj_frames = a["inter"], MAX_CYCLE
                 L.agcn_w_pairs, L.agcn_b_pairs, L.agcn_a_sum = a["w_pairs"].data_ptr(), a["b_pairs"].data_ptr(), a["a_sum"].data_ptr()
                 L.agcn_adj = adj.data_ptr()
                 L.ell_val = None
@@ -608,7 +640,7 @@ class CoStGcn(_Folded):
                 return
         c, _, v, m = self.input_shape
         arr, keep, ops, fcw, fcb = self._layer_structs(device)
-        plan = native.lib().csk_co_plan_create(10, ctypes.byref(arr), native.ptr(self._xin0), self._n, c, v, m, self._p,
+        plan = native.lib().csk_co_plan_create(10, ctypes.byref(arr), native.ptr(self._xin0), self._xin0.shape[0], self._n, c, v, m, self._p,
                                                native.ptr(ops["scale"]), native.ptr(ops["shift"]), self.num_classes,
                                                native.ptr(fcw), native.ptr(fcb), self.pool_size, self.pool_padding,
                                                native.ptr(self._pool_ring), native.ptr(self._pooled))
@@ -616,7 +648,7 @@ class CoStGcn(_Folded):
             raise RuntimeError("csk_co_plan_create: " + native.lib().csk_last_error().decode())
         self.__dict__["_plan"] = plan
         self._install_dirty_hooks()
-        self.__dict__["_plan_keep"] = (keep, self._weights_version(), list(self.parameters()) + list(self.buffers()))
+        self.__dict__["_plan_keep"] = (keep, self._weight_slots())
         self.__dict__.pop("_weights_dirty", None)
         fuse = all(self.layers[f"layer{i + 1}"].fuse_step for i in range(10))
         native.check(native.lib().csk_co_plan_set_fusion(plan, int(fuse)), "csk_co_plan_set_fusion")
@@ -629,8 +661,7 @@ class CoStGcn(_Folded):
         rc = native.lib().csk_co_plan_update_weights(self._plan, 10, ctypes.byref(arr), native.ptr(ops["scale"]),
                                                      native.ptr(ops["shift"]), native.ptr(fcw), native.ptr(fcb))
         native.check(rc, "csk_co_plan_update_weights")
-        self.__dict__["_plan_keep"] = (keep, self._weights_version(), list(self.parameters()) + list(self.buffers()))
-        self.__dict__["_verify_pos"] = 0
+        self.__dict__["_plan_keep"] = (keep, self._weight_slots())
 
     def _destroy_plan(self):
         plan = self.__dict__.pop("_plan", None)
@@ -650,8 +681,10 @@ class CoStGcn(_Folded):
             self._xin0.numel() + self._pool_ring.numel())
 
     def scratch_bytes(self):
-        """Transient split-K scratch (shared by the blocks that split their K loop); not state."""
-        return 4 * self._scratch.numel() if self._scratch is not None else 0
+        """Transient scratch, not state: the split-K partial sums (shared by the blocks that split their K loop) and, for
+        adaptive graph convs, the per-skeleton-frame adjacencies of a launch (shared by all blocks)."""
+        adj = self.__dict__.get("_agcn_adj")
+        return 4 * ((self._scratch.numel() if self._scratch is not None else 0) + (adj.numel() if adj is not None else 0))
 
     def clean_state(self):
         if self._n is not None:
@@ -745,7 +778,7 @@ class CoStGcn(_Folded):
         n, c, v, m = frames[0].shape
         ops = self._packed_ops(frames[0].device)
         for x_t in frames:
-            dst = self._xin0[self._frames % HIST]
+            dst = self._xin0[self._frames % self._xin0.shape[0]]
             # reshape1 + data_bn + reshape2 (base.py:73-82) straight into the channel-major input ring
             rc = native.lib().csk_input_norm_f32(native.ptr(x_t), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
                                                  native.ptr(dst), n, c, 1, v, m, v, self._p, native.stream_of(x_t))
@@ -757,9 +790,9 @@ class CoStGcn(_Folded):
             if res is None:
                 return None, 0, []
             r = res[1]
-        outs = []
+        outs, depth = [], self.layers["layer10"]._state.out.shape[0]
         for j in range(res[1]):
-            o = self._head_step((res[0] + j) % HIST, n)
+            o = self._head_step((res[0] + j) % depth, n)
             if o is not None:
                 outs.append(o)
         return res[0], res[1], outs
@@ -845,7 +878,7 @@ class CoStGcn(_Folded):
         """End padding of the whole model (``pad_end=True``): returns the predictions it releases.  Runs on the Python
         engine; a native plan's counters are read before and written back afterwards.  The flush ends the sequence: it
         zeroes y-ring slots and advances the per-block counters by their padding while the input frame count stays,
-        so the rings no longer line up with ``frames % HIST`` -- the model is marked flushed and the next step raises
+        so the rings no longer line up with ``frames % depth`` -- the model is marked flushed and the next step raises
         until ``clean_state()`` (continual-inference's own end padding does not save state either; a caller that wants
         to go on uses ``update_state=False``, which runs the flush on a snapshot)."""
         plan = self.__dict__.get("_plan")
@@ -858,19 +891,23 @@ class CoStGcn(_Folded):
                 st.s, st.e = int(buf[2 + 2 * i]), int(buf[3 + 2 * i])
         n = self._n
         _, _, v, m = self.input_shape
-        outs = []
+        outs, depth = [], self.layers["layer10"]._state.out.shape[0]
         for i in range(10):
             blk = self.layers[f"layer{i + 1}"]
-            res = blk.engine_advance(blk.padding, n * m, v, flush=True) if blk.padding else None
-            for j in range(i + 1, 10):             # what block i released travels down the rest of the stack
-                if res is None:
-                    break
-                res = self.layers[f"layer{j + 1}"].engine_advance(res[1], n * m, v)
-            if res is not None:
-                for jj in range(res[1]):
-                    o = self._head_step((res[0] + jj) % HIST, n)
-                    if o is not None:
-                        outs.append(o)
+            left = blk.padding
+            while left:                                # at most max_in frames per launch (ring depths); order is unchanged
+                r = min(left, blk._state.max_in)
+                left -= r
+                res = blk.engine_advance(r, n * m, v, flush=True)
+                for j in range(i + 1, 10):             # what block i released travels down the rest of the stack
+                    if res is None:
+                        break
+                    res = self.layers[f"layer{j + 1}"].engine_advance(res[1], n * m, v)
+                if res is not None:
+                    for jj in range(res[1]):
+                        o = self._head_step((res[0] + jj) % depth, n)
+                        if o is not None:
+                            outs.append(o)
         for _ in range(self.pool_padding):         # co.AvgPool1d end padding: zero features enter the window
             o = self._head_step(None, n)
             if o is not None:

@@ -14,6 +14,7 @@ struct csk_co_plan {
     std::vector<csk_co_layer> layers;
     std::vector<BlockCounters> cnt;
     float *xin0;
+    int xin0_slots;
     int N, C, V, M, classes, pool_size, pool_padding;
     int64_t P;
     const float *bn_scale, *bn_shift, *fc_w, *fc_b;
@@ -22,8 +23,8 @@ struct csk_co_plan {
     bool fuse = true;          // csk_co_block_step_f32 for the blocks that qualify
 };
 
-extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int N, int C, int V,
-                                           int M, int64_t P, const float *bn_scale, const float *bn_shift, int classes,
+extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int xin0_slots, int N, int C,
+                                           int V, int M, int64_t P, const float *bn_scale, const float *bn_shift, int classes,
                                            const float *fc_w, const float *fc_b, int pool_size, int pool_padding,
                                            float *pool_ring, float *pooled) {
     if (n_layers <= 0 || !layers || !xin0 || N <= 0 || C <= 0 || V < 2 || M <= 0 || P < (int64_t)N * M * V || (P & 3) ||
@@ -31,6 +32,31 @@ extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *lay
         pool_padding >= pool_size || !pool_ring || !pooled) {
         snprintf(csk_err_buf(), 256, "co_plan_create: bad argument");
         return nullptr;
+    }
+    if (xin0_slots < CSK_CO_IN_SLOTS(CSK_CO_MAX_CYCLE)) {
+        snprintf(csk_err_buf(), 256, "co_plan_create: the input ring needs >= %d slots, got %d", CSK_CO_IN_SLOTS(CSK_CO_MAX_CYCLE), xin0_slots);
+        return nullptr;
+    }
+    // ring depths against the frames one launch of each layer can receive / emit (include/cskel.h: CSK_CO_Y_SLOTS, CSK_CO_IN_SLOTS)
+    for (int i = 0, max_in = CSK_CO_MAX_CYCLE; i < n_layers; ++i) {
+        const csk_co_layer &l = layers[i];
+        if (l.stride < 1 || l.stride > 2) break;                              // reported by the per-layer checks below
+        const int max_emit = max_in / l.stride > 0 ? max_in / l.stride : 1;
+        const int want_out = i + 1 < n_layers ? CSK_CO_IN_SLOTS(max_emit) : max_emit;
+        if (l.y_slots < CSK_CO_Y_SLOTS(max_in) || l.out_slots < want_out) {
+            snprintf(csk_err_buf(), 256, "co_plan_create: layer %d rings too shallow: y_slots %d (need >= %d), out_slots %d (need >= %d)", i,
+                     l.y_slots, CSK_CO_Y_SLOTS(max_in), l.out_slots, want_out);
+            return nullptr;
+        }
+        if (l.tcn_ksplit > 1 && l.partial_emits < 1) {
+            snprintf(csk_err_buf(), 256, "co_plan_create: layer %d splits its K loop but partial_emits is %d", i, l.partial_emits);
+            return nullptr;
+        }
+        if (l.agcn_inter > 0 && l.agcn_adj_frames < 1) {
+            snprintf(csk_err_buf(), 256, "co_plan_create: layer %d has an adaptive graph conv but agcn_adj_frames is %d", i, l.agcn_adj_frames);
+            return nullptr;
+        }
+        max_in = max_emit;
     }
     for (int i = 0; i < n_layers; ++i) {
         const csk_co_layer &l = layers[i];
@@ -50,7 +76,7 @@ extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *lay
     csk_co_plan *p = new csk_co_plan();
     p->layers.assign(layers, layers + n_layers);
     p->cnt.resize(n_layers);
-    p->xin0 = xin0; p->N = N; p->C = C; p->V = V; p->M = M; p->P = P;
+    p->xin0 = xin0; p->xin0_slots = xin0_slots; p->N = N; p->C = C; p->V = V; p->M = M; p->P = P;
     p->bn_scale = bn_scale; p->bn_shift = bn_shift; p->classes = classes; p->fc_w = fc_w; p->fc_b = fc_b;
     p->pool_size = pool_size; p->pool_padding = pool_padding;
     p->pool_ring = pool_ring; p->pooled = pooled;
@@ -67,7 +93,9 @@ extern "C" int csk_co_plan_update_weights(csk_co_plan *plan, int n_layers, const
     for (int i = 0; i < n_layers; ++i) {
         const csk_co_layer &o = plan->layers[i], &n = layers[i];
         if (o.c_in != n.c_in || o.c_out != n.c_out || o.stride != n.stride || o.res_kind != n.res_kind ||
-            o.y_ring != n.y_ring || o.out_ring != n.out_ring || o.agcn_inter != n.agcn_inter || o.agcn_adj != n.agcn_adj)
+            o.y_ring != n.y_ring || o.out_ring != n.out_ring || o.agcn_inter != n.agcn_inter || o.agcn_adj != n.agcn_adj ||
+            o.y_slots != n.y_slots || o.out_slots != n.out_slots || o.partial_emits != n.partial_emits ||
+            o.tcn_partial != n.tcn_partial || o.agcn_adj_frames != n.agcn_adj_frames)
             CSK_FAIL("co_plan_update_weights: layer %d geometry/state differs", i);
     }
     plan->layers.assign(layers, layers + n_layers);
@@ -102,19 +130,23 @@ extern "C" void csk_co_plan_reset(csk_co_plan *plan) {
     plan->frames = plan->feats = 0;
 }
 
-// one block: r frames are already in xin[(s .. s+r-1) % HIST]; returns emissions via *slot0 / *n_emit
-static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *xin, int r, int n_frames, int V,
+// one block: r frames are already in xin[(s .. s+r-1) % HIST] (HIST = depth of the input ring = the upstream layer's
+// out_slots); returns emissions via *slot0 / *n_emit
+static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *xin, int HIST, int r, int n_frames, int V,
                          int64_t P, int *slot0, int *n_emit, bool fuse, void *stream) {
     constexpr int K = 9, DELAY = 4, LAG = 4;      // padding="equal": delay = k-1-p = 4; residual lag (k-1)/2
+    const int YRING = l.y_slots, OUT = l.out_slots;
     const long s0 = c.s;
+    if (r + K - 1 > YRING || r + LAG > HIST)
+        CSK_FAIL("co_plan_cycle: %d frames do not fit the rings of a layer (y ring %d slots, input ring %d)", r, YRING, HIST);
     // one fused launch for a whole emitting 4-frame cycle of a 64-row block (continual.py:_fusable)
     if (fuse && l.agcn_inter == 0 && r == 4 && l.stride == 1 && l.c_out <= 64 && s0 >= DELAY && l.res_kind != CSK_RES_CONV && l.tcn_ksplit <= 1 &&
         l.ell_cnt[0] <= 1 && l.ell_cnt[1] <= 1 && l.ell_cnt[2] <= 4 && ((64 + V - 2) / V + 1) * V <= 128) {
-        *slot0 = (int)(c.e % CSK_CO_HIST);
-        const int rc = csk_co_block_step_f32(xin, CSK_CO_HIST, (int)(s0 % CSK_CO_HIST), l.c_in, l.gcn_w, l.gcn_bias,
-                                         l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, l.gcn_res_mode, l.y_ring, CSK_CO_YRING,
-                                         (int)(s0 % CSK_CO_YRING), l.tcn_w, l.tcn_bias, l.res_kind,
-                                         (int)((s0 - LAG) % CSK_CO_HIST), l.out_ring, CSK_CO_HIST, *slot0, l.c_out, n_frames, V, P,
+        *slot0 = (int)(c.e % OUT);
+        const int rc = csk_co_block_step_f32(xin, HIST, (int)(s0 % HIST), l.c_in, l.gcn_w, l.gcn_bias,
+                                         l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, l.gcn_res_mode, l.y_ring, YRING,
+                                         (int)(s0 % YRING), l.tcn_w, l.tcn_bias, l.res_kind,
+                                         (int)((s0 - LAG) % HIST), l.out_ring, OUT, *slot0, l.c_out, n_frames, V, P,
                                          stream);
         if (rc) return rc;
         c.s += 4; c.e += 4;
@@ -124,12 +156,13 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
     for (int f = 0; f < r;) {                      // per-frame graph conv, one launch per non-wrapping slot run
         const long s = s0 + f;
         int run = r - f;
-        if (run > CSK_CO_HIST - (int)(s % CSK_CO_HIST)) run = CSK_CO_HIST - (int)(s % CSK_CO_HIST);
-        if (run > CSK_CO_YRING - (int)(s % CSK_CO_YRING)) run = CSK_CO_YRING - (int)(s % CSK_CO_YRING);
-        const float *xs = xin + (s % CSK_CO_HIST) * (int64_t)l.c_in * P;
-        float *ys = l.y_ring + (s % CSK_CO_YRING) * (int64_t)l.c_out * P;
+        if (run > HIST - (int)(s % HIST)) run = HIST - (int)(s % HIST);
+        if (run > YRING - (int)(s % YRING)) run = YRING - (int)(s % YRING);
+        const float *xs = xin + (s % HIST) * (int64_t)l.c_in * P;
+        float *ys = l.y_ring + (s % YRING) * (int64_t)l.c_out * P;
         int rc;
         if (l.agcn_inter > 0) {
+            if (run > l.agcn_adj_frames) CSK_FAIL("co_plan_cycle: %d frames of adjacencies do not fit agcn_adj (%d frames)", run, l.agcn_adj_frames);
             // adaptive graph conv (continual-skeletons_amd/agcn.py:AdaptiveGraphConvolution.stage): the adjacency of every
             // skeleton frame of the run, then the graph conv with it
             rc = csk_agcn_embed_attention_f32(xs, l.agcn_w_pairs, l.agcn_b_pairs, l.agcn_a_sum, l.agcn_adj, nullptr, run, l.c_in,
@@ -152,10 +185,13 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
     *n_emit = 0;
     if (first < 0) return 0;
     const int ne = (int)((s0 + r - 1 - first) / l.stride) + 1;
-    *slot0 = (int)(c.e % CSK_CO_HIST);
-    const int rc = csk_tcn_step_f32(l.y_ring, CSK_CO_YRING, (int)(first % CSK_CO_YRING), l.stride, ne, l.tcn_w,
-                                    l.res_kind ? xin : nullptr, CSK_CO_HIST, (int)((first - LAG) % CSK_CO_HIST), l.stride,
-                                    l.tcn_w_res, l.tcn_bias, l.out_ring, CSK_CO_HIST, *slot0, l.c_out, l.c_out, P, K,
+    if (ne > OUT) CSK_FAIL("co_plan_cycle: %d emissions do not fit an output ring of %d slots", ne, OUT);
+    if (l.tcn_ksplit > 1 && ne > l.partial_emits)
+        CSK_FAIL("co_plan_cycle: %d emissions exceed the split-K scratch of the layer (%d emissions)", ne, l.partial_emits);
+    *slot0 = (int)(c.e % OUT);
+    const int rc = csk_tcn_step_f32(l.y_ring, YRING, (int)(first % YRING), l.stride, ne, l.tcn_w,
+                                    l.res_kind ? xin : nullptr, HIST, (int)((first - LAG) % HIST), l.stride,
+                                    l.tcn_w_res, l.tcn_bias, l.out_ring, OUT, *slot0, l.c_out, l.c_out, P, K,
                                     l.res_kind, l.res_kind ? l.c_in : 0, 1, l.tcn_ksplit > 1 ? l.tcn_ksplit : 1, l.tcn_partial,
                                     stream);
     if (rc) return rc;
@@ -167,15 +203,16 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
 // the ten blocks for r new frames: *n_last emissions of the last block starting at output-ring slot *slot0
 static int run_blocks(csk_co_plan *p, int r, int *slot0, int *n_last, void *stream) {
     const float *xin = p->xin0;
-    int rr = r;
+    int rr = r, in_slots = p->xin0_slots;
     *n_last = 0;
     for (size_t i = 0; i < p->layers.size(); ++i) {
         int ne = 0;
-        const int rc = advance_block(p->layers[i], p->cnt[i], xin, rr, p->N * p->M, p->V, p->P, slot0, &ne, p->fuse, stream);
+        const int rc = advance_block(p->layers[i], p->cnt[i], xin, in_slots, rr, p->N * p->M, p->V, p->P, slot0, &ne, p->fuse, stream);
         if (rc) return rc;
         if (ne == 0) return 0;
         rr = ne;
         xin = p->layers[i].out_ring;
+        in_slots = p->layers[i].out_slots;
     }
     *n_last = rr;
     return 0;
@@ -196,7 +233,7 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
     } rollback{p, p->frames, p->feats, p->cnt};
     for (int f = 0; f < r; ++f) {                  // reshape1 + data_bn + reshape2 into the channel-major ring
         if (!frames[f]) CSK_FAIL("co_plan_cycle: null frame");
-        float *dst = p->xin0 + (p->frames % CSK_CO_HIST) * (int64_t)p->C * p->P;
+        float *dst = p->xin0 + (p->frames % p->xin0_slots) * (int64_t)p->C * p->P;
         const int rc = csk_input_norm_f32(frames[f], p->bn_scale, p->bn_shift, dst, p->N, p->C, 1, p->V, p->M, p->V, p->P,
                                           stream);
         if (rc) return rc;
@@ -210,7 +247,7 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
     const csk_co_layer &last = p->layers.back();
     const int64_t n_elem = (int64_t)p->N * last.c_out;
     for (int j = 0; j < rr; ++j) {                 // spatial_pool -> co.AvgPool1d window -> co.Linear
-        const int slot = (slot0 + j) % CSK_CO_HIST;
+        const int slot = (slot0 + j) % last.out_slots;
         const int head = (int)(p->feats % p->pool_size);
         int rc = csk_co_spatial_pool_f32(last.out_ring + slot * (int64_t)last.c_out * p->P, p->pool_ring + head * n_elem,
                                          p->N, last.c_out, p->M * p->V, p->P, stream);

@@ -84,7 +84,9 @@ extern "C" int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_
                           int classes, void *stream) {
     if (!feat || !fc_w || !fc_b || !logits) CSK_FAIL("fc: null pointer");
     if (N <= 0 || C <= 0 || classes <= 0) CSK_FAIL("fc: bad dims");
-    if ((reinterpret_cast<uintptr_t>(feat) & 15) || (reinterpret_cast<uintptr_t>(fc_w) & 15)) CSK_FAIL("fc: feat / fc_w must be 16-byte aligned");
+    // the 16-byte loads of the C % 4 == 0 path need 16-byte aligned rows; other channel counts take the scalar loop
+    if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(feat) & 15) || (reinterpret_cast<uintptr_t>(fc_w) & 15)))
+        CSK_FAIL("fc: feat / fc_w must be 16-byte aligned when C is a multiple of 4");
     const int ktiles = (classes + 63) / 64;
     const int64_t waves = (int64_t)N * ktiles;
     hipLaunchKernelGGL(fc_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feat, fc_w, fc_b,

@@ -308,19 +308,37 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     p.vec_stage = !csk_diag_flag("CSK_TCN_NOVEC");
     // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
     p.fast_epi = (int64_t)p.Tres * V < (1ll << 27) && (int64_t)t_out * V < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
-    const bool big = (p.Mpad % 128) == 0;
-    const int MT = big ? 128 : 64, NT = 16384 / MT;
     // the register staging holds <= 9 (128-row tiles) / 14 (64-row tiles) x 64 positions of an activation row -- the
     // widest spill-free instantiations; tiles whose input span (stride * frames + k taps) * V is longer than that
-    // (stride 3 with V > 32, ...) are narrowed: a tile then covers p.nt < NT output positions and the remaining MFMA
-    // columns idle.  Never the case for the ST-GCN shapes (V <= 25, stride <= 2).
+    // (stride 2 with V > 32, stride 3, ...) are narrowed: a tile then covers nt < NT output positions and the remaining
+    // MFMA columns idle.  Never the case for the ST-GCN shapes (V <= 25, stride <= 2).  Both tile heights are priced
+    // (the 64-row kernel stages 14 sweeps: at V = 64, stride 2 it keeps 128 of its 256 columns where the 128-row kernel
+    // keeps 1 of 128) and the better MFMA-column utilisation wins; a shape that loses more than half the columns either
+    // way says so once on stderr.
+    auto narrow = [&](int NT_, int nj_max_, int *ldb_) {
+        int nt = NT_;
+        for (;;) {
+            const int max_dt = (nt + V - 2) / V;
+            *ldb_ = round_up((stride * max_dt + k) * V, 4);
+            if ((*ldb_ + 63) / 64 <= nj_max_ || nt == 1) return nt;
+            nt = nt > 16 ? nt - 16 : nt > 1 ? nt / 2 : 1;
+        }
+    };
+    bool big = (p.Mpad % 128) == 0;
+    int ldb64 = 0, ldb128 = 0;
+    const int nt64 = narrow(256, 14, &ldb64), nt128 = big ? narrow(128, 9, &ldb128) : 0;
+    if (big && nt128 < 128 && nt64 * 128 > nt128 * 256) big = false;       // utilisation nt64 / 256 > nt128 / 128
+    const int MT = big ? 128 : 64, NT = 16384 / MT;
     const int nj_max = big ? 9 : 14;
-    p.nt = NT;
-    for (;;) {
-        const int max_dt = (p.nt + V - 2) / V;
-        p.ldb = round_up((stride * max_dt + k) * V, 4);
-        if ((p.ldb + 63) / 64 <= nj_max || p.nt == 1) break;
-        p.nt = p.nt > 16 ? p.nt - 16 : 1;
+    p.nt = big ? nt128 : nt64;
+    p.ldb = big ? ldb128 : ldb64;
+    if (2 * p.nt < NT) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "libcskel_hip: tcn_stage with V = %d, stride %d, k = %d keeps %d of %d tile columns (activation span "
+                            "exceeds the staged maximum): correct, but far below the kernel's rate\n", V, stride, k, p.nt, NT);
+        }
     }
     const int nj = (p.ldb + 63) / 64;
     if (nj > nj_max) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (%d)", p.ldb, 64 * nj_max);

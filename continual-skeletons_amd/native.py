@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 # name -> argtypes; mirrors include/cskel.h line by line
@@ -34,7 +34,7 @@ SIGNATURES = {
     "csk_co_window_mean_f32": [_p, _p, _l, _i, _i, _i, _p],
 
     "csk_fuse_rank_f32": [_p, _i, _i, _i, _i, _l, _l, _p, _p, _p, _p],
-    "csk_co_plan_create": [_i, _p, _p, _i, _i, _i, _i, _l, _p, _p, _i, _p, _p, _i, _i, _p, _p],
+    "csk_co_plan_create": [_i, _p, _p, _i, _i, _i, _i, _i, _l, _p, _p, _i, _p, _p, _i, _i, _p, _p],
     "csk_co_plan_destroy": [_p],
     "csk_co_plan_update_weights": [_p, _i, _p, _p, _p, _p, _p],
     "csk_co_plan_reset": [_p],
@@ -49,6 +49,7 @@ class CoLayer(C.Structure):
     """Mirror of ``csk_co_layer`` (include/cskel.h)."""
     _fields_ = [("c_in", C.c_int32), ("c_out", C.c_int32), ("stride", C.c_int32), ("res_kind", C.c_int32),
                 ("gcn_res_mode", C.c_int32), ("ell_w", C.c_int32), ("ell_cnt", C.c_int32 * 3), ("tcn_ksplit", C.c_int32),
+                ("y_slots", C.c_int32), ("out_slots", C.c_int32), ("partial_emits", C.c_int32), ("agcn_adj_frames", C.c_int32),
                 ("gcn_w", C.c_void_p), ("gcn_bias", C.c_void_p), ("ell_src", C.c_void_p), ("ell_val", C.c_void_p),
                 ("tcn_w", C.c_void_p), ("tcn_w_res", C.c_void_p), ("tcn_bias", C.c_void_p),
                 ("y_ring", C.c_void_p), ("out_ring", C.c_void_p), ("tcn_partial", C.c_void_p),

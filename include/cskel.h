@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 11
+#define CSK_ABI_VERSION 12
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -166,7 +166,8 @@ int csk_pool_fc_f32(const float *h, const float *fc_w, const float *fc_b, float 
  * (spatial_pool + zero-padded co.AvgPool1d window, models/base.py:84-97,166-181) uses scale = frames/pool_size */
 int csk_pool_scaled_f32(const float *h, float *feat, int N, int M, int C, int TV, float scale, void *stream);
 
-/* plain FC on pooled features: logits[n] = feat[n] @ fc_w^T + fc_b  (co.Linear, models/base.py:99) */
+/* plain FC on pooled features: logits[n] = feat[n] @ fc_w^T + fc_b  (co.Linear, models/base.py:99).  When C is a
+ * multiple of 4 the rows are read 16 bytes at a time: feat and fc_w must then be 16-byte aligned (an error otherwise). */
 int csk_fc_f32(const float *feat, const float *fc_w, const float *fc_b, float *logits,
                int N, int C, int classes, void *stream);
 
@@ -283,24 +284,37 @@ int csk_fuse_rank_f32(const float *const *preds, int n_streams, int use_max, int
  * frames (input norm, per block one GCN-stage + one multi-emission TCN-step launch, spatial pool, temporal
  * window mean, FC), with the ring-slot / stride-phase bookkeeping kept in the plan.  No allocation, no sync.
  * ------------------------------------------------------------------------------------------------ */
-#define CSK_CO_HIST 16   /* depth of input / output history rings  */
-#define CSK_CO_YRING 16  /* depth of the post-GCN rings            */
 #define CSK_CO_MAX_CYCLE 8
+/* Ring depths are per layer (csk_co_layer.y_slots / .out_slots, csk_co_plan_create xin0_slots), derived from the frames ONE
+ * launch of the layer can receive (max_in = CSK_CO_MAX_CYCLE / cumulative stride of the layers in front of it):
+ *   post-GCN ring   : the (k-1) = 8 window frames of co.Conv2d + the new frames      -> CSK_CO_Y_SLOTS(max_in)
+ *   input history   : residual lag (k-1)/2 = 4 (co.Delay / residual_shrink) + the new frames -> CSK_CO_IN_SLOTS(max_in);
+ *                     a layer's output ring IS the next layer's input history, so out_slots(l) = CSK_CO_IN_SLOTS(max_in(l+1))
+ *                     (last layer: at least its own emissions per launch; csk_co_block_step_f32 wants >= 4).
+ * A frame s lives in slot s % depth of its ring.  Deeper rings are accepted. */
+#define CSK_CO_Y_SLOTS(max_in) (8 + (max_in))
+#define CSK_CO_IN_SLOTS(max_in) (4 + (max_in))
 
 typedef struct csk_co_layer {
     int32_t c_in, c_out, stride, res_kind;   /* res_kind: CSK_RES_NONE / IDENTITY / CONV (block residual) */
     int32_t gcn_res_mode, ell_w, ell_cnt[3];
     int32_t tcn_ksplit;                      /* split-K of the TCN step (csk_tcn_step_f32); 1 = off               */
+    int32_t y_slots, out_slots;              /* depths of y_ring / out_ring (see CSK_CO_Y_SLOTS / CSK_CO_IN_SLOTS)  */
+    int32_t partial_emits;                   /* emissions the split-K scratch holds (0 when tcn_ksplit == 1)       */
+    int32_t agcn_adj_frames;                 /* frames of per-skeleton adjacencies agcn_adj holds (0: no adaptive graph conv) */
     const float *gcn_w, *gcn_bias;           /* packed operands of csk_gcn_stage_f32                       */
     const int32_t *ell_src;
     const float *ell_val;
     const float *tcn_w, *tcn_w_res, *tcn_bias; /* packed operands of csk_tcn_step_f32                      */
-    float *y_ring;                           /* [CSK_CO_YRING][c_out][P]                                   */
-    float *out_ring;                         /* [CSK_CO_HIST][c_out][P]; input history of the next layer   */
-    float *tcn_partial;                      /* [CSK_CO_MAX_CYCLE * tcn_ksplit][c_out][P] or NULL (tcn_ksplit == 1) */
+    float *y_ring;                           /* [y_slots][c_out][P]                                        */
+    float *out_ring;                         /* [out_slots][c_out][P]; input history of the next layer     */
+    float *tcn_partial;                      /* [partial_emits * tcn_ksplit][c_out][P] or NULL (tcn_ksplit == 1): raw partial sums
+                                              * of the emissions ONE launch of this layer produces (may be shared by all
+                                              * layers: launches are stream-ordered); a cycle whose launch would emit more
+                                              * fails with an error instead of overrunning it */
     /* adaptive graph conv (CoAGCN, models/coa_gcn/coa_gcn.py:11-14); agcn_inter == 0: plain GraphConvolution.  Otherwise the
      * layer's adjacency is computed per skeleton frame by csk_agcn_embed_attention_f32 (per-frame form) into agcn_adj
-     * ([CSK_CO_MAX_CYCLE * skeletons][3][V][V] floats, may be shared by all layers: launches are stream-ordered) and ell_src /
+     * ([agcn_adj_frames * skeletons][3][V][V] floats, may be shared by all layers: launches are stream-ordered) and ell_src /
      * ell_w / ell_cnt describe the dense pattern (ell_w = V, ell_cnt = {V, V, V}); ell_val is not used. */
     int32_t agcn_inter, agcn_pad_;
     const float *agcn_w_pairs, *agcn_b_pairs, *agcn_a_sum;
@@ -309,9 +323,9 @@ typedef struct csk_co_layer {
 
 typedef struct csk_co_plan csk_co_plan;
 
-/* xin0: [CSK_CO_HIST][C][P] input ring of layer 0.  pool_ring: [pool_size][N][feat_c]; pooled: [N][feat_c];
- */
-csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int N, int C, int V, int M,
+/* xin0: [xin0_slots][C][P] input ring of layer 0 (xin0_slots >= CSK_CO_IN_SLOTS(CSK_CO_MAX_CYCLE)).
+ * pool_ring: [pool_size][N][feat_c]; pooled: [N][feat_c]. */
+csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int xin0_slots, int N, int C, int V, int M,
                                 int64_t P, const float *bn_scale, const float *bn_shift, int classes,
                                 const float *fc_w, const float *fc_b, int pool_size, int pool_padding,
                                 float *pool_ring, float *pooled);

@@ -253,6 +253,43 @@ def test_native_plan_equals_python_engine_and_survives_weight_reload():
     assert all(torch.equal(p, q) for p, q in zip(outs[True], outs[False]))
 
 
+@pytest.mark.parametrize("edit", ["replace_parameter", "swap_submodule", "in_place", "data_assign"])
+def test_native_plan_sees_every_kind_of_weight_edit_at_once(edit):
+    """The native plan's operands are refolded on the FIRST cycle after a weight edit that no hook can see: a replaced
+    Parameter object, a swapped sub-module, an in-place edit, ``p.data = ...``.  After the edit the native plan and the
+    Python engine (which refolds from the live modules on every launch) must agree bitwise on every later prediction,
+    and the predictions must differ from those of the unedited weights."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:2, :, :120].to(DEV)
+    outs = {}
+    for native_plan, edited in ((True, True), (False, True), (True, False)):
+        co = pkg.CoStGcn(A, pool_size=4, pool_padding=1).eval()
+        co.use_native_plan = native_plan
+        co.load_state_dict(sd, strict=True)
+        co = co.to(DEV)
+        got = []
+        for t in range(0, 120, 4):
+            if t == 96 and edited:
+                with torch.no_grad():
+                    if edit == "replace_parameter":
+                        co.fc.weight = torch.nn.Parameter(co.fc.weight.detach() * 1.5)
+                    elif edit == "swap_submodule":
+                        old = co.layers["layer3"].tcn.bn
+                        new = torch.nn.BatchNorm2d(old.num_features).to(DEV).eval()
+                        new.load_state_dict({k: (v * 1.25 if k == "weight" else v) for k, v in old.state_dict().items()})
+                        co.layers["layer3"].tcn.bn = new
+                    elif edit == "in_place":
+                        co.fc.bias.add_(0.5)
+                    else:
+                        co.layers["layer10"].tcn.t_conv.weight.data = co.layers["layer10"].tcn.t_conv.weight.data * 1.25
+            got += co.forward_cycle([x[:, :, t + f].contiguous() for f in range(4)])
+        outs[(native_plan, edited)] = got
+    nat, py, plain = outs[(True, True)], outs[(False, True)], outs[(True, False)]
+    assert len(nat) == len(py) == len(plain) >= 8
+    assert all(torch.equal(p, q) for p, q in zip(nat, py))
+    assert torch.equal(nat[0], plain[0]) and not torch.equal(nat[-1], plain[-1])      # the edit took effect
+
+
 class _ForeignGraphConv(torch.nn.Module):
     """A graph conv the package knows nothing about (stands for the spatial-attention module S-TR passes as
     ``GraphConv`` / ``CoGraphConv``, models/base.py:338-349,390-400): plain PyTorch ops, no ``stage`` method."""
@@ -458,7 +495,7 @@ def test_fused_block_step_small_and_ragged_channels(ci, co, res):
         x = torch.rand((4, ci, p), generator=g).to(DEV)
         for st in (sa, sb):
             for f in range(4):
-                st.xin[(st.s + f) % 16] = x[f]
+                st.xin[(st.s + f) % st.xin.shape[0]] = x[f]
         ra, rb = a.engine_advance(4, n_skel, 25), b.engine_advance(4, n_skel, 25)
         assert ra == rb
         assert torch.equal(sa.y, sb.y) and torch.equal(sa.out, sb.out), cyc

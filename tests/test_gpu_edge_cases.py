@@ -49,6 +49,29 @@ def test_block_edge_shapes(ci, co, stride, res, T, N, v):
     check_parity(got, want, shape=(ci, co, stride, res, T, N, v))
 
 
+@pytest.mark.parametrize("c,co,stride,v,T", [
+    (128, 128, 2, 40, 21),     # 128-row tiles narrowed (span of a stride-2 tile exceeds 9 sweeps of 64 positions)
+    (128, 128, 2, 64, 13),     # V = 64: the 64-row kernel (14 sweeps) keeps half its columns, the 128-row one would keep 1
+    (16, 128, 3, 48, 17),      # stride 3
+    (8, 64, 2, 64, 9),         # 64-row tiles narrowed
+])
+def test_temporal_conv_wide_skeletons_narrowed_tiles(c, co, stride, v, T):
+    """csk_tcn_stage_f32 on shapes whose activation span per tile exceeds the register staging (V > 32 with stride >= 2):
+    the tile is narrowed / the other tile height is chosen (csrc/tcn.hip); results must not depend on that choice."""
+    torch.manual_seed(c + v)
+    m = pkg.TemporalConvolution(c, co, 9, stride, 4).eval()
+    with torch.no_grad():
+        m.t_conv.weight.mul_(0.3)
+        m.bn.weight.uniform_(0.5, 1.5); m.bn.bias.uniform_(-0.5, 0.5)
+        m.bn.running_mean.uniform_(-0.5, 0.5); m.bn.running_var.uniform_(0.5, 1.5)
+    sd = {k: t.clone() for k, t in m.state_dict().items()}
+    x = torch.rand(2, c, T, v)
+    with torch.no_grad():
+        want = o.temporal_conv(x, sd, "", stride, 4)
+    got = m.to(DEV)(x.to(DEV)).cpu()
+    check_parity(got, want, shape=(c, co, stride, v, T))
+
+
 @pytest.mark.parametrize("T,pad", [(9, 0), (10, 0), (12, 2)])
 def test_unpadded_block_minimal_lengths(T, pad):
     """temporal_padding < 4: the clip must be at least k - 2p frames long; output length T + 2p - 8."""

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cskel.h but not exported"
     assert declared - {"csk_last_error"} == set(pkg.native.SIGNATURES), "ctypes table out of sync with cskel.h"
-    assert pkg.native.lib().csk_abi_version() == pkg.native.ABI_VERSION == 11
+    assert pkg.native.lib().csk_abi_version() == pkg.native.ABI_VERSION == 12
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -321,6 +321,11 @@ def test_set_precision_marks_blocks_and_refolds():
     assert m.layers["layer5"]._fold()["w_split"] is None
     with pytest.raises(ValueError):
         pkg.set_precision(m, "fp16")
+    # a block the split kernel does not cover anywhere below the module: refused BEFORE any block is switched
+    m.layers["layer9"].tcn.kernel_size = 7
+    with pytest.raises(NotImplementedError):
+        pkg.set_precision(m, "bf16x3")
+    assert all(b.precision == "f32" for b in m.layers.values())
 
 
 def test_gcn_bf16x3_entry_validates_arguments_without_a_gpu():
@@ -362,14 +367,66 @@ def test_fused_attention_entry_and_plan_validate_their_arguments_without_a_gpu()
     for f in ("gcn_w", "gcn_bias", "ell_src", "tcn_w", "tcn_bias", "y_ring", "out_ring"):
         setattr(l, f, 0x1000)
     l.agcn_inter, l.agcn_w_pairs, l.agcn_b_pairs, l.agcn_a_sum = 16, 0x1000, 0x1000, 0x1000      # agcn_adj missing
+    l.y_slots, l.out_slots, l.agcn_adj_frames = 16, 8, 8
     lib.csk_co_plan_create.restype = C.c_void_p
-    plan = lib.csk_co_plan_create(1, C.byref(L), fake, 2, 3, 18, 2, 72, fake, fake, 400, fake, fake, 4, 1, fake, fake)
-    assert not plan and b"adaptive graph conv" in lib.csk_last_error()
+
+    def create(xin0_slots=12):
+        return lib.csk_co_plan_create(1, C.byref(L), fake, xin0_slots, 2, 3, 18, 2, 72, fake, fake, 400, fake, fake, 4, 1, fake, fake)
+    assert not create() and b"adaptive graph conv" in lib.csk_last_error()
     l.agcn_adj = 0x1000
     l.ell_w = 6                                          # not the dense pattern
-    plan = lib.csk_co_plan_create(1, C.byref(L), fake, 2, 3, 18, 2, 72, fake, fake, 400, fake, fake, 4, 1, fake, fake)
-    assert not plan and b"adaptive graph conv" in lib.csk_last_error()
+    assert not create() and b"adaptive graph conv" in lib.csk_last_error()
     l.ell_w = 18
-    plan = lib.csk_co_plan_create(1, C.byref(L), fake, 2, 3, 18, 2, 72, fake, fake, 400, fake, fake, 4, 1, fake, fake)
+    # ring depths (include/cskel.h: CSK_CO_Y_SLOTS / CSK_CO_IN_SLOTS) and scratch capacities are part of the contract
+    assert not create(xin0_slots=11) and b"input ring needs >= 12" in lib.csk_last_error()
+    l.y_slots = 15
+    assert not create() and b"rings too shallow" in lib.csk_last_error()
+    l.y_slots, l.out_slots = 16, 7
+    assert not create() and b"rings too shallow" in lib.csk_last_error()
+    l.out_slots, l.agcn_adj_frames = 8, 0
+    assert not create() and b"agcn_adj_frames" in lib.csk_last_error()
+    l.agcn_adj_frames, l.tcn_ksplit, l.tcn_partial, l.partial_emits = 8, 3, 0x1000, 0
+    assert not create() and b"partial_emits" in lib.csk_last_error()
+    l.partial_emits = 8
+    plan = create()
     assert plan
     lib.csk_co_plan_destroy(C.c_void_p(plan))
+
+
+def test_plan_staleness_check_is_exact_for_every_kind_of_weight_edit():
+    """CoStGcn._weights_changed (host logic of the native plan): exact on the FIRST call after a replaced Parameter, a
+    swapped / added sub-module, an in-place edit and ``p.data = ...`` -- checked on the snapshot the plan keeps, without a
+    GPU (the plan itself is not built here)."""
+    import torch
+    pkg = _bootstrap.load()
+
+    def fresh():
+        net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+        net.__dict__["_plan_keep"] = (None, net._weight_slots())
+        assert net._weights_changed() is False and net._weights_changed() is False
+        return net
+
+    net = fresh()
+    net.fc.weight = torch.nn.Parameter(net.fc.weight.detach().clone())
+    assert net._weights_changed() is True
+    net = fresh()
+    net.layers["layer3"].tcn.bn = torch.nn.BatchNorm2d(64).eval()
+    assert net._weights_changed() is True
+    net = fresh()
+    with torch.no_grad():
+        net.fc.bias.add_(1.0)
+    assert net._weights_changed() is True
+    net = fresh()
+    net.layers["layer10"].tcn.t_conv.weight.data = net.layers["layer10"].tcn.t_conv.weight.data.clone()
+    assert net._weights_changed() is True
+    net = fresh()
+    net.layers["layer1"].gcn.register_buffer("extra", torch.zeros(1))
+    net.layers["layer2"].add_module("extra", torch.nn.Identity())
+    assert net._weights_changed() is True
+    net = fresh()
+    net.load_state_dict(net.state_dict())
+    net._install_dirty_hooks()
+    net.load_state_dict(net.state_dict())
+    assert net._weights_changed() is True
+    net.__dict__["_plan_keep"] = (None, net._weight_slots())          # what _refresh_plan_weights does after refolding
+    assert net._weights_changed() is False

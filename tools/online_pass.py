@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Workload of the online-path profile passes (tools/profile_online.sh): EXACTLY bench.py's online shape --
+"""Workload of the online-path profile passes (tools/profile_r04.sh): EXACTLY bench.py's online shape --
 CoST-GCN, 1024 streams, cycles of 4 frames, native plan -- from a clean state, warm-up cycles included (the trace
 summariser tools/summarize_layers.py keeps the last --cycles cycles of every HIP stream, which are steady state:
 all ten blocks emit, the temporal pool is full).
