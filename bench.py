@@ -344,6 +344,60 @@ def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2, cpu_thread
                               "roofline_config": workmodel.roofline_config(sfa, sby, step_dt, sfe), "cpu_baseline": cpu_step}}
 
 
+def run_latency(pkg, dev, cpu_step, stream_counts=(1, 16), frames=400):
+    """Few-stream latency of the online path (the reference's own CPU protocol is batch 1: scripts/benchmark_all_ntu60.py:17):
+    one frame at a time through CoStGcn.forward_step in latency mode (set_latency_mode: split-K on launches too small to
+    fill the GPU), host-synchronised after every frame so that a sample is the whole submit -> result time of a frame.
+    p50 / p99 over `frames` steady-state frames; `pipelined_ms_per_frame` = the same frames without per-frame
+    synchronisation (throughput of a single stream set)."""
+    import statistics
+    out = []
+    for streams in stream_counts:
+        net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+        randomise_(net, seed=0)
+        net = net.to(dev)
+        net.set_latency_mode(8)
+        x = torch.rand((8, streams, NTU["C"], NTU["V"], NTU["M"]), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+        for t in range(76 + 4 * 56):               # warm-up + fill the temporal pool: every frame class (4 phases) is steady
+            net.forward_step(x[t % 8])
+        torch.cuda.synchronize()
+        ts, preds = [], 0
+        for t in range(frames):
+            t0 = time.perf_counter()
+            o = net.forward_step(x[t % 8])
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            preds += o is not None
+        t0 = time.perf_counter()
+        for t in range(frames):
+            net.forward_step(x[t % 8])
+        torch.cuda.synchronize()
+        piped = (time.perf_counter() - t0) / frames
+        ts.sort()
+        # launches of one 4-frame stride cycle in per-frame stepping: input norm per frame; per block one graph-conv launch
+        # per received frame and one temporal-conv launch (+ the split-K reduction) per emission; the head's three launches
+        # on the predicting frame
+        launches, recv = 4.0, 4.0
+        for i in range(10):
+            blk = net.layers[f"layer{i + 1}"]
+            emit = recv / blk.stride
+            launches += recv + emit * (2 if blk._state.ksplit > 1 else 1)
+            recv = emit
+        launches += 3
+        out.append({"streams": streams, "frames_timed": frames, "predictions": preds,
+                    "ms_per_frame_p50": round(statistics.median(ts) * 1e3, 4), "ms_per_frame_p99": round(ts[int(0.99 * (frames - 1))] * 1e3, 4),
+                    "ms_per_frame_mean": round(sum(ts) / frames * 1e3, 4), "pipelined_ms_per_frame": round(piped * 1e3, 4),
+                    "launches_per_frame": round(launches / 4, 2),
+                    "split_k": [net.layers[f"layer{i + 1}"]._state.ksplit for i in range(10)]})
+        del net, x
+        gc.collect()
+        torch.cuda.empty_cache()
+    cpu_ms = round(1e3 / cpu_step["value"], 4) if cpu_step and cpu_step.get("value") else None
+    return {"mode": "CoStGcn.forward_step, one frame per call, set_latency_mode(8), synchronised after every frame",
+            "per_stream_count": out, "cpu_oracle_ms_per_frame_one_stream": cpu_ms,
+            "note": "frames 1-3 of a stride cycle run fewer blocks than the 4th (strides 2, 2): p99 is the predicting frame"}
+
+
 def load_traffic(name="traffic_tcn_stage.json"):
     """Per-launch HBM bytes of the dominant kernel from the COMMITTED PMC summary (profiles/; separate rocprofv3 --pmc
     passes of tools/profile.sh -- not measured by this run, the line says so under `traffic_source`), or None."""
@@ -406,6 +460,8 @@ def main():
                          "measured 982 k -> 1015 k frames/s; four exceed the hardware queues)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the opt-in bf16x3 precision-mode leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the 1- and 16-stream per-frame latency leg of the online workload")
+    ap.add_argument("--latency-frames", type=int, default=400, help="frames timed per stream count by the latency leg")
     ap.add_argument("--cpu-budget", type=float, default=50.0, help="seconds of CPU work the configs[1]/[2] cpu_baseline legs may take in all")
     ap.add_argument("--cpu-budget-config4", type=float, default=14.0, help="seconds of CPU work for the two configs[3] cpu_baseline legs")
     args = ap.parse_args()
@@ -634,13 +690,18 @@ def main():
                                   if straffic and straffic.get("streams") == args.streams else None},
                      "roofline_config": workmodel.roofline_config(sfa * world, sby * world, sdt / args.step_cycles, sfe * world),
                      "throughput_mode": thr, "cpu_baseline": cpu_step, "config": "BASELINE.json configs[2]"}
+        if world == 1 and not args.no_latency_leg:
+            gc.collect()
+            torch.cuda.empty_cache()
+            step_info["latency"] = run_latency(pkg, dev, cpu_step, frames=args.latency_frames)
         if line is None:          # --workload step: the online metric is the primary one
             line = {"metric": step_info["metric"], "value": step_info["value"], "unit": "frames/s", "n_gpus": world,
                     "steps": args.step_cycles, "warmup": 2, "ms_per_step": round(sdt / args.step_cycles * 1e3, 3),
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                     "config": {"workload": f"CoST-GCN online step, {args.streams} streams/GPU, NTU-60, one step = {args.frames_per_launch} frames [configs[2]]",
                                "parallelism": f"stream-shard x{world}"},
-                    "roofline": step_info["roofline"], "roofline_config": step_info["roofline_config"], "cpu_baseline": cpu_step}
+                    "roofline": step_info["roofline"], "roofline_config": step_info["roofline_config"], "cpu_baseline": cpu_step,
+                    "latency": step_info.get("latency")}
         else:
             line["costgcn_online"] = step_info
     if do_clip and do_step and world == 1:          # BASELINE.json configs[3] beside the headline numbers (per GPU)

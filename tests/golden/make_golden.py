@@ -7,8 +7,9 @@ outputs are data (inputs, state_dicts, expected outputs) stored as .npz.
 The reference imports `ride`, `pytorch_lightning` and `continual`, none of which is installed.
 They are replaced by *name-only* stubs (no arithmetic) so that the clip-path classes --
 GraphConvolution, TemporalConvolution, SpatioTemporalBlock (models/base.py:230-387),
-AdaptiveGraphConvolution (models/a_gcn/a_gcn.py:12-69), Graph (datasets/graph.py) and
-StGcn.__init__/forward (models/st_gcn/st_gcn.py:20-65) -- execute verbatim.
+AdaptiveGraphConvolution (models/a_gcn/a_gcn.py:12-69), Graph (datasets/graph.py),
+StGcn.__init__/forward (models/st_gcn/st_gcn.py:20-65) and the key map CoModelBase.map_state_dict
+(models/base.py:200-224, pure string code) -- execute verbatim.
 
 BatchNorm affine/statistics and graph_attn are RANDOMISED: with the default init
 (gcn.bn.weight = 1e-6, models/base.py:256-257) the whole aggregation branch is invisible at 1e-4.
@@ -247,7 +248,51 @@ def generate():
     # G8 -- full AGcn (models/a_gcn/a_gcn.py:72-145), Kinetics shape, N=1: closed-form weights including non-trivial
     #       a_conv / b_conv (the per-sample attention), logits + layer 1/5/8/10 taps
     out["g8_agcn_kin"] = _whole_model(R, R.AGcn, R.A_kin, G8["V"], G8["classes"], G8["n"], G8["seed"], G8["gcn_bn_scale"])
+    # G9 -- CoModelBase.map_state_dict (models/base.py:200-224), the reference's regular -> continual key map: pure
+    #       string code, executed UNBOUND on a stub nn.Module whose state_dict keys are the continual key layout
+    out["g9_key_map"] = _key_map(R)
     return out
+
+
+def _co_key(k: str) -> str:
+    """Continual-layout name of a regular ST-GCN key, from the container structure of CoSpatioTemporalBlock
+    (models/base.py:412-446) as the reference's tests spell it out (tests/test_cost_gcn.py:97-98,145,193-198,299-311):
+    residual=False -> Sequential(gcn, tcn, relu): unchanged; identity residual -> Sequential(Residual(Sequential(gcn,
+    tcn)), relu): ``0.1.gcn`` / ``0.1.tcn``; conv residual -> Sequential(BroadcastReduce(Sequential(residual, align),
+    Sequential(gcn, tcn)), relu): ``0.0.residual`` and ``0.1.gcn`` / ``0.1.tcn``."""
+    parts = k.split(".")
+    if parts[0] != "layers" or parts[1] == "layer1":                       # layer1: residual=False (st_gcn.py:30)
+        return k
+    head, rest = ".".join(parts[:2]), parts[2:]
+    return ".".join([head, "0", "0" if rest[0] == "residual" else "1"] + rest)
+
+
+def _key_map(R):
+    from models.base import CoModelBase
+    reg = R.StGcn.__new__(R.StGcn)
+    nn.Module.__init__(reg)
+    reg.input_shape, reg.num_classes, reg.graph = (3, 300, 25, 2), 60, types.SimpleNamespace(A=R.A_ntu)
+    torch.manual_seed(9)
+    R.StGcn.__init__(reg, {})
+    regular = list(reg.state_dict().keys())
+    co_keys = [_co_key(k) for k in regular]
+    stub = nn.Module()                                     # a module tree whose state_dict() has exactly the continual keys
+    for k in co_keys:
+        m, parts = stub, k.split(".")
+        for prt in parts[:-1]:
+            if prt not in m._modules:
+                m.add_module(prt, nn.Module())
+            m = m._modules[prt]
+        m.register_buffer(parts[-1], torch.zeros(1))
+    assert list(nn.Module.state_dict(stub).keys()) == co_keys
+    sd = {k: i for i, k in enumerate(regular)}             # values: positions, so that the fixture also pins the pairing
+    strict = CoModelBase.map_state_dict(stub, dict(sd), strict=True)
+    loose = CoModelBase.map_state_dict(stub, dict(sd, **{"not.a.key": -1}), strict=False)
+    same = CoModelBase.map_state_dict(stub, {k: i for i, k in enumerate(co_keys)}, strict=True)   # already continual: returned as is
+    return dict(regular_keys=np.array(regular), co_keys=np.array(co_keys),
+                mapped_strict_keys=np.array(list(strict.keys())), mapped_strict_pos=np.array(list(strict.values())),
+                mapped_loose_keys=np.array(list(loose.keys())), mapped_loose_pos=np.array(list(loose.values())),
+                mapped_same_keys=np.array(list(same.keys())))
 
 
 def verify():

@@ -24,7 +24,7 @@ def _run(*args):
 def test_bench_line_contract(workload):
     d = _run("--workload", workload, "--batch", "4", "--streams", "8", "--steps", "2", "--warmup", "1", "--step-cycles", "2",
              "--stream-shards", "2", "--cpu-budget", "6", "--config4-batch", "2", "--config4-streams", "6",
-             "--cpu-budget-config4", "4")
+             "--cpu-budget-config4", "4", "--latency-frames", "12")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -51,3 +51,9 @@ def test_bench_line_contract(workload):
         b3 = k["agcn_clip"]["bf16x3"]                     # opt-in mode of the A-GCN clip leg: its own key
         assert b3["value"] > 0 and "bf16x3" in b3["dtype"] and b3["max_abs_logit_diff_vs_f32"] < 1e-4
         assert d["costgcn_online"]["roofline_config"]["frac"] > 0
+    if workload in ("step", "both"):      # few-stream latency leg (the reference's batch-1 protocol): 1 and 16 streams
+        lat = (d if workload == "step" else d["costgcn_online"]).get("latency") or d.get("costgcn_online", {}).get("latency")
+        assert lat and [e["streams"] for e in lat["per_stream_count"]] == [1, 16]
+        for e in lat["per_stream_count"]:
+            assert 0 < e["ms_per_frame_p50"] <= e["ms_per_frame_p99"] and e["launches_per_frame"] > 10 and e["predictions"] == 3
+        assert lat["cpu_oracle_ms_per_frame_one_stream"] > 0

@@ -75,6 +75,28 @@ def test_costgcn_keys_and_map_state_dict():
     assert (co.receptive_field, co.padding, co.stride, co.pool_size, co.pool_padding) == (153, 76, 4, 75, 19)
 
 
+def test_costgcn_key_map_matches_the_reference_fixture():
+    """G9 (tests/golden/make_golden.py): the continual key layout and the output of the reference's own
+    CoModelBase.map_state_dict (models/base.py:200-224, executed unbound on a stub with that layout) on the reference
+    StGcn's keys.  CoStGcn must expose the same keys in the same order and map a regular state dict the same way:
+    strict, non-strict (unknown keys dropped) and already-continual (returned as is)."""
+    import numpy as np
+    d = np.load(os.path.join(ROOT, "tests", "golden", "g9_key_map.npz"))
+    regular, co_keys = [str(k) for k in d["regular_keys"]], [str(k) for k in d["co_keys"]]
+    net = pkg.CoStGcn(pkg.ntu_graph().A)
+    assert list(net.state_dict().keys()) == co_keys
+    assert list(pkg.StGcn(pkg.ntu_graph().A).state_dict().keys()) == regular
+    sd = {k: i for i, k in enumerate(regular)}
+    strict = net.map_state_dict(dict(sd), strict=True)
+    assert list(strict.keys()) == [str(k) for k in d["mapped_strict_keys"]] and list(strict.values()) == list(d["mapped_strict_pos"])
+    loose = net.map_state_dict(dict(sd, **{"not.a.key": -1}), strict=False)
+    assert list(loose.keys()) == [str(k) for k in d["mapped_loose_keys"]] and list(loose.values()) == list(d["mapped_loose_pos"])
+    with pytest.raises(KeyError):                                   # the reference raises on an unknown key when strict
+        net.map_state_dict(dict(sd, **{"not.a.key": -1}), strict=True)
+    same = net.map_state_dict({k: i for i, k in enumerate(co_keys)}, strict=True)
+    assert list(same.keys()) == [str(k) for k in d["mapped_same_keys"]] == co_keys
+
+
 def test_load_pretrained_pt_and_ckpt(tmp_path):
     """Weight import path: a regular ST-GCN state dict saved as .pt, or inside a Lightning-style
     .ckpt, loads into StGcn and -- through map_loaded_weights (models/base.py:226-227) -- into CoStGcn; a state
