@@ -162,9 +162,19 @@ class GraphConvolution(_Folded):
         gcn_stage(x, y, ops, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v))
         return y
 
-    def stage(self, x, y, n_seg, frames, x_strides, y_strides):
-        """Launch on explicit views/strides (used by the continual engine on its channel-major rings)."""
-        gcn_stage(x, y, self._packed_ops(x.device), n_seg=n_seg, frames=frames, x_strides=x_strides, y_strides=y_strides)
+    def stage(self, x, y, n_seg, frames, x_strides, y_strides, ksplit=1, partial=None):
+        """Launch on explicit views/strides (used by the continual engine on its channel-major rings).  ``ksplit`` > 1
+        (latency mode): the K loop is split over workgroups through ``partial`` (csk_gcn_stage_splitk_f32)."""
+        ops = self._packed_ops(x.device)
+        if ksplit > 1:
+            rc = native.lib().csk_gcn_stage_splitk_f32(
+                native.ptr(x), native.ptr(y), native.ptr(ops["w"]), native.ptr(ops["bias"]), native.ptr(ops["ell_src"]),
+                native.ptr(ops["ell_val"]), native.ptr(ops["ell_cnt_host"]), ops["ell_w"], n_seg, ops["c_in"], ops["c_out"], frames,
+                ops["V"], x_strides[0], x_strides[1], y_strides[0], y_strides[1], ops["res_mode"], ksplit, native.ptr(partial),
+                native.stream_of(x))
+            native.check(rc, "csk_gcn_stage_splitk_f32")
+            return
+        gcn_stage(x, y, ops, n_seg=n_seg, frames=frames, x_strides=x_strides, y_strides=y_strides)
 
 
 def gcn_stage(x, y, ops, n_seg, frames, x_strides, y_strides, adj_seg_stride=0, adj_per_frame=0):

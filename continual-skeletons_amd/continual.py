@@ -131,23 +131,25 @@ class _BlockState:
     """Slice of the state slab owned by one block: y ring, output ring, (optionally own) input ring, counters."""
 
     def __init__(self, c_in, c_out, k, p, device, xin=None, ksplit=1, max_emit=MAX_CYCLE, scratch=None, max_in=MAX_CYCLE,
-                 out_slots=None):
+                 out_slots=None, gcn_ksplit=1):
         self.p = p
         self.ksplit = ksplit
+        self.gcn_ksplit = gcn_ksplit      # split-K of the graph conv (latency mode); shares the partial-sum buffer
         # split-K scratch of the TCN step: raw partial sums of the emissions ONE launch can produce (max_emit: MAX_CYCLE
         # for a stand-alone block, MAX_CYCLE / cumulative stride inside a stack).  Launches are stream-ordered, so a
         # stack shares one scratch buffer (``scratch``, sized by its largest user) instead of one per block.
         self.max_emit = max_emit
-        self.owns_partial = ksplit > 1 and scratch is None
-        need = max_emit * ksplit * c_out * p
-        if ksplit <= 1:
+        self.owns_partial = (ksplit > 1 or gcn_ksplit > 1) and scratch is None
+        slabs = max(max_emit * ksplit if ksplit > 1 else 0, max_in * gcn_ksplit if gcn_ksplit > 1 else 0)   # [c_out][p] each
+        need = slabs * c_out * p
+        if slabs == 0:
             self.partial = None
         elif scratch is not None:
             if scratch.numel() < need:
                 raise ValueError(f"shared split-K scratch holds {scratch.numel()} floats, block needs {need}")
-            self.partial = scratch[:need].view(max_emit * ksplit, c_out, p)
+            self.partial = scratch[:need].view(slabs, c_out, p)
         else:
-            self.partial = torch.empty((max_emit * ksplit, c_out, p), device=device, dtype=torch.float32)
+            self.partial = torch.empty((slabs, c_out, p), device=device, dtype=torch.float32)
         # ring depths from what ONE launch can receive / emit (y_slots / in_slots above); a stand-alone block keeps an
         # output ring deep enough for max_emit emissions (and the 4 a fused cycle writes)
         self.max_in = max_in
@@ -248,13 +250,14 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         the consuming block needs as its input history); ``scratch`` = split-K scratch shared with the other blocks."""
         self._state = _BlockState(self.in_channels, self.out_channels, self.kernel_size, p, device, xin,
                                   ksplit=self._pick_ksplit(p), max_emit=max_emit, scratch=scratch, max_in=max_in,
-                                  out_slots=out_slots)
+                                  out_slots=out_slots, gcn_ksplit=self._pick_gcn_ksplit(p))
         return self._state
 
-    def scratch_floats(self, p: int, max_emit: int = MAX_CYCLE) -> int:
-        """Split-K scratch this block needs for launches of up to ``max_emit`` emissions (0 without split-K)."""
-        ks = self._pick_ksplit(p)
-        return max_emit * ks * self.out_channels * p if ks > 1 else 0
+    def scratch_floats(self, p: int, max_emit: int = MAX_CYCLE, max_in: int = MAX_CYCLE) -> int:
+        """Split-K scratch this block needs for launches of up to ``max_in`` received frames / ``max_emit`` emissions
+        (0 without split-K)."""
+        ks, gks = self._pick_ksplit(p), self._pick_gcn_ksplit(p)
+        return max(max_emit * ks if ks > 1 else 0, max_in * gks if gks > 1 else 0) * self.out_channels * p
 
     split_k = 0     # 0: no split-K; n > 1: latency mode -- up to n channel ranges per tile when a launch is too small
 
@@ -276,7 +279,23 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         tiles = -(-p // (16384 // mt)) * (-(-self.out_channels // mt))
         if tiles >= 64:
             return base
-        return max(base, min(self.split_k, 16, (-(-self.out_channels // 8)) // 2))
+        # up to 4 * split_k ranges (<= 32) while a split keeps at least one 8-channel chunk and the launch stays below
+        # ~256 workgroups: a 9-tap chunk is 3.8 us of MFMAs for one workgroup, and with a handful of tiles the other
+        # 250 CUs are idle anyway
+        want = min(4 * self.split_k, 32, -(-self.out_channels // 8), max(1, 256 // tiles))
+        return max(base, want)
+
+    def _pick_gcn_ksplit(self, p: int) -> int:
+        """Split-K factor of this block's graph conv (csk_gcn_stage_splitk_f32), latency mode only: with a handful of
+        streams one workgroup per tile walks all 3 * C_in / 8 K-chunks alone (52 us at C_in = 256 -- 60 % of a frame's
+        latency at one stream, profiles/r04_latency_1stream.md); a function of (C_in, split_k) only."""
+        if self.split_k <= 1 or type(self.gcn) is not GraphConvolution or self.in_channels < 16:
+            return 1
+        mt = 128 if self.out_channels % 128 == 0 else 64
+        tiles = -(-p // (16384 // mt)) * (-(-self.out_channels // mt))
+        if tiles >= 64:
+            return 1
+        return max(1, min(4 * self.split_k, 32, -(-self.in_channels // 8), max(1, 256 // tiles)))
 
     def clean_state(self):
         if self._state is not None:
@@ -304,6 +323,10 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
             run = min(r - f, HIST - s % HIST, YRING - s % YRING)
             if flush:
                 st.y[s % YRING: s % YRING + run].zero_()
+            elif st.gcn_ksplit > 1:
+                self.gcn.stage(st.xin[s % HIST], st.y[s % YRING], n_seg=run, frames=n_frames,
+                               x_strides=(self.in_channels * p, p), y_strides=(self.out_channels * p, p),
+                               ksplit=st.gcn_ksplit, partial=st.partial)
             elif hasattr(self.gcn, "stage"):
                 self.gcn.stage(st.xin[s % HIST], st.y[s % YRING], n_seg=run, frames=n_frames,
                                x_strides=(self.in_channels * p, p), y_strides=(self.out_channels * p, p))
@@ -339,7 +362,8 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         """csk_co_block_step_f32 (include/cskel.h): 64-row blocks, stride 1, a whole 4-frame cycle of emitting steps,
         native sparse graph conv, block residual none / identity, no split-K."""
         if not (self.fuse_step and r == 4 and self.stride == 1 and self.out_channels <= 64 and s0 >= self.delay
-                and self.kind in ("none", "identity") and type(self.gcn) is GraphConvolution and self._state.ksplit == 1):
+                and self.kind in ("none", "identity") and type(self.gcn) is GraphConvolution and self._state.ksplit == 1
+                and self._state.gcn_ksplit == 1):
             return False
         g = self.gcn._packed_ops(self._state.y.device)
         cnt = g["ell_cnt_host"]
@@ -508,7 +532,7 @@ class CoStGcn(_Folded):
             recv.append(max(1, MAX_CYCLE // cum))
             cum *= self.layers[f"layer{i + 1}"].stride
             emits.append(max(1, MAX_CYCLE // cum))
-        need = max(self.layers[f"layer{i + 1}"].scratch_floats(p, emits[i]) for i in range(10))
+        need = max(self.layers[f"layer{i + 1}"].scratch_floats(p, emits[i], recv[i]) for i in range(10))
         self._scratch = torch.empty((need,), device=device, dtype=torch.float32) if need else None
         for i in range(10):
             out_slots = in_slots(recv[i + 1]) if i < 9 else max(4, emits[i])
@@ -607,7 +631,8 @@ class CoStGcn(_Folded):
             L.y_ring, L.out_ring = st.y.data_ptr(), st.out.data_ptr()
             L.tcn_ksplit = st.ksplit
             L.y_slots, L.out_slots = st.y.shape[0], st.out.shape[0]
-            L.partial_emits = st.max_emit if st.partial is not None else 0
+            L.partial_emits = st.max_emit if (st.partial is not None and st.ksplit > 1) else 0
+            L.gcn_ksplit, L.gcn_partial_frames = st.gcn_ksplit, (st.max_in if st.gcn_ksplit > 1 else 0)
             L.tcn_partial = st.partial.data_ptr() if st.partial is not None else None
             L.agcn_inter = L.agcn_adj_frames = 0
             if type(blk.gcn) is not GraphConvolution:      # adaptive graph conv: adjacency per skeleton frame (agcn.py)

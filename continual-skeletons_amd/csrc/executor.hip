@@ -48,6 +48,10 @@ extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *lay
                      l.y_slots, CSK_CO_Y_SLOTS(max_in), l.out_slots, want_out);
             return nullptr;
         }
+        if (l.gcn_ksplit > 1 && (l.gcn_partial_frames < 1 || !l.tcn_partial || l.agcn_inter > 0)) {
+            snprintf(csk_err_buf(), 256, "co_plan_create: layer %d splits its graph conv but has no partial-sum buffer (or an adaptive graph conv)", i);
+            return nullptr;
+        }
         if (l.tcn_ksplit > 1 && l.partial_emits < 1) {
             snprintf(csk_err_buf(), 256, "co_plan_create: layer %d splits its K loop but partial_emits is %d", i, l.partial_emits);
             return nullptr;
@@ -95,7 +99,8 @@ extern "C" int csk_co_plan_update_weights(csk_co_plan *plan, int n_layers, const
         if (o.c_in != n.c_in || o.c_out != n.c_out || o.stride != n.stride || o.res_kind != n.res_kind ||
             o.y_ring != n.y_ring || o.out_ring != n.out_ring || o.agcn_inter != n.agcn_inter || o.agcn_adj != n.agcn_adj ||
             o.y_slots != n.y_slots || o.out_slots != n.out_slots || o.partial_emits != n.partial_emits ||
-            o.tcn_partial != n.tcn_partial || o.agcn_adj_frames != n.agcn_adj_frames)
+            o.tcn_partial != n.tcn_partial || o.agcn_adj_frames != n.agcn_adj_frames || o.gcn_ksplit != n.gcn_ksplit ||
+            o.gcn_partial_frames != n.gcn_partial_frames)
             CSK_FAIL("co_plan_update_weights: layer %d geometry/state differs", i);
     }
     plan->layers.assign(layers, layers + n_layers);
@@ -141,6 +146,7 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
         CSK_FAIL("co_plan_cycle: %d frames do not fit the rings of a layer (y ring %d slots, input ring %d)", r, YRING, HIST);
     // one fused launch for a whole emitting 4-frame cycle of a 64-row block (continual.py:_fusable)
     if (fuse && l.agcn_inter == 0 && r == 4 && l.stride == 1 && l.c_out <= 64 && s0 >= DELAY && l.res_kind != CSK_RES_CONV && l.tcn_ksplit <= 1 &&
+        l.gcn_ksplit <= 1 &&
         l.ell_cnt[0] <= 1 && l.ell_cnt[1] <= 1 && l.ell_cnt[2] <= 4 && ((64 + V - 2) / V + 1) * V <= 128) {
         *slot0 = (int)(c.e % OUT);
         const int rc = csk_co_block_step_f32(xin, HIST, (int)(s0 % HIST), l.c_in, l.gcn_w, l.gcn_bias,
@@ -171,6 +177,12 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
             rc = csk_gcn_stage_f32(xs, ys, l.gcn_w, l.gcn_bias, l.ell_src, l.agcn_adj, l.ell_cnt, l.ell_w, (int64_t)3 * V * V, 1,
                                    run, l.c_in, l.c_out, n_frames, V, (int64_t)l.c_in * P, P, (int64_t)l.c_out * P, P,
                                    l.gcn_res_mode, stream);
+        } else if (l.gcn_ksplit > 1) {
+            if (run > l.gcn_partial_frames)
+                CSK_FAIL("co_plan_cycle: %d frames exceed the split-K scratch of the layer's graph conv (%d frames)", run, l.gcn_partial_frames);
+            rc = csk_gcn_stage_splitk_f32(xs, ys, l.gcn_w, l.gcn_bias, l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, run, l.c_in, l.c_out,
+                                          n_frames, V, (int64_t)l.c_in * P, P, (int64_t)l.c_out * P, P, l.gcn_res_mode, l.gcn_ksplit,
+                                          l.tcn_partial, stream);
         } else {
             rc = csk_gcn_stage_f32(xs, ys, l.gcn_w, l.gcn_bias, l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, 0, 0, run, l.c_in,
                                    l.c_out, n_frames, V, (int64_t)l.c_in * P, P, (int64_t)l.c_out * P, P, l.gcn_res_mode, stream);

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_stage_kernel(const GcnParams 
 // ------------------------------------------------------------------------------------------------
 // PLAIN: the same pipeline as a bare 1 x 1 conv (one "subset" with the identity adjacency, no residual, no ReLU) -- the six
 // a_i / b_i embedding convs of A-GCN fused into one GEMM (models/a_gcn/a_gcn.py:53-59), csk_conv1x1_f32.
-template <int MT, bool CONVRES, int KCG_, bool PLAIN = false>
+// SPLIT: one of p.ksplit channel ranges of a tile (raw partial sums, no epilogue arithmetic): csk_gcn_stage_splitk_f32.
+template <int MT, bool CONVRES, int KCG_, bool PLAIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const GcnParams p) {
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
@@ -270,7 +271,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
     const int l31 = lane & 31, kh = lane >> 5;
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * NT;
-    const int seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int segks = (int)(wid / (p.mtiles * p.qtiles));
+    const int seg = SPLIT ? segks / p.ksplit : segks, ks = SPLIT ? segks % p.ksplit : 0;
+    const int cb = SPLIT ? ks * p.cper : 0;                // first channel of this split
     const int Q = p.frames * V;
     const int qend = min(q0 + NT, Q);
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
     const float *seg_base = p.x + (int64_t)seg * p.x_seg_stride;
-    const float *wbase = p.w + m0;
+    const float *wbase = p.w + m0 + (size_t)cb * p.Mpad;
     // staging registers + chunk-invariant offsets
     f32x4 wv[WB];
     unsigned wgo[WB], wlo[WB];
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
             wv[i] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)c0 * p.Mpad + wgo[i]);
         } else {
             const int rr = (i - WB) / NX, u = (i - WB) % NX;
-            const int c = min(c0 + wave + rr * (NTHREADS / 64), p.Cin - 1);
+            const int c = min(cb + c0 + wave + rr * (NTHREADS / 64), p.Cin - 1);
             const float *row = seg_base + (int64_t)c * p.x_chan_stride;
             if (VEC) bv4[rr][u] = *reinterpret_cast<const f32x4u *>(row + bgo4[u]);
             else bv[rr][u] = row[bgo[u]];
@@ -406,7 +409,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
         }
     };
 
-    const int nchunks = p.CinPad / KCG_;                   // CinPad is a multiple of CSK_CPAD = 16
+    // CinPad is a multiple of CSK_CPAD = 16; a split covers cper (a multiple of KCG_) channels, the last one what is left
+    const int nchunks = (SPLIT ? min(p.CinPad - cb, p.cper) : p.CinPad) / KCG_;
     auto k_loop = [&](auto vtag) {
         constexpr int NLX = WB + RPW * (decltype(vtag)::value ? NJ4 : NJ);     // staging loads per thread per chunk
 #pragma unroll
@@ -450,12 +454,15 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
     const int rbase = m0 + wm * 64;
     const bool full = p.fast_epi && m0 + MT <= p.Cout;
     const unsigned kh4 = 4u * (unsigned)kh;
-    float *oseg = p.y + (int64_t)seg * p.y_seg_stride;
+    float *oseg = SPLIT ? p.part + (int64_t)(seg * p.ksplit + ks) * p.Cout * p.y_chan_stride : p.y + (int64_t)seg * p.y_seg_stride;
     const int qb = q0 + wn * 64 + lane;
     const bool qv = qb < Q;
     float bb[2][16], rv[2][2][16];
     auto load_half = [&](int mi) {
-        if (full) {
+        if (SPLIT) {                        // raw partial sums: bias, residual and ReLU belong to gcn_reduce_kernel
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bb[mi][g] = rv[0][mi][g] = rv[1][mi][g] = 0.f;
+        } else if (full) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) bb[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gcn_stage_sparse2_kernel(const Gc
         for (int g = 0; g < 16; ++g) {
             float v0 = acc[mi][0][g] + bb[mi][g] + rv[0][mi][g];
             float v1 = acc[mi][1][g] + bb[mi][g] + rv[1][mi][g];
-            if (!PLAIN) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
+            if (!PLAIN && !SPLIT) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
             acc[mi][0][g] = __uint_as_float(sw[0]);       // row (g & 3) + 8*(g >> 2), column qb
             acc[mi][1][g] = __uint_as_float(sw[1]);       // row + 4
@@ -751,15 +758,29 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gcn_stage_dense_kernel(const Gc
     }
 }
 
+// split-K reduction of the GCN stage: y[seg][co][q] = ReLU( sum_ks part[seg * ksplit + ks][co][q] (split order) + bias[co]
+// + identity gcn_residual x[seg][co][q] ); one thread per (co, q), q < Q = frames * V
+__global__ __launch_bounds__(256) void gcn_reduce_kernel(const GcnParams p) {
+    const int Q = p.frames * p.V;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)p.Cout * Q) return;
+    const int co = (int)(i / Q), q = (int)(i - (int64_t)co * Q), seg = blockIdx.y;
+    float s = 0.f;
+    for (int ks = 0; ks < p.ksplit; ++ks) s += p.part[((int64_t)(seg * p.ksplit + ks) * p.Cout + co) * p.y_chan_stride + q];
+    s += p.bias[co];
+    if (p.res_mode == CSK_RES_IDENTITY) s += p.x[(int64_t)seg * p.x_seg_stride + (int64_t)co * p.x_chan_stride + q];
+    p.y[(int64_t)seg * p.y_seg_stride + (int64_t)co * p.y_chan_stride + q] = relu_nan(s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
-                                 const float *ell_val, const int32_t *ell_cnt, int ell_w, int64_t adj_seg_stride,
-                                 int adj_per_frame,
-                                 int n_seg, int c_in, int c_out, int frames, int V, int64_t x_seg_stride,
-                                 int64_t x_chan_stride, int64_t y_seg_stride, int64_t y_chan_stride, int res_mode,
-                                 void *stream) {
+static int gcn_stage_impl(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
+                          const float *ell_val, const int32_t *ell_cnt, int ell_w, int64_t adj_seg_stride,
+                          int adj_per_frame,
+                          int n_seg, int c_in, int c_out, int frames, int V, int64_t x_seg_stride,
+                          int64_t x_chan_stride, int64_t y_seg_stride, int64_t y_chan_stride, int res_mode,
+                          int ksplit, float *partial, void *stream) {
     if (!x || !y || !w || !bias || !ell_src || !ell_val || !ell_cnt) CSK_FAIL("gcn_stage: null pointer");
     if (n_seg <= 0 || c_in <= 0 || c_out <= 0 || frames <= 0 || V < 2 || V > 64) CSK_FAIL("gcn_stage: bad dims");
     if (ell_w < 1 || ell_w > V) CSK_FAIL("gcn_stage: ell_w must be in [1, V]");
@@ -800,17 +821,37 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     // sparse-graph fast path: shared adjacency with <= 1/1/4 non-zeros per column, activation tile <= 320 positions
     const bool sparse = adj_seg_stride == 0 && ell_cnt[0] <= 1 && ell_cnt[1] <= 1 && ell_cnt[2] <= 4 && p.ldb <= (big ? 192 : 320) &&
                         !csk_diag_flag("CSK_GCN_GENERAL");
+    // split-K (latency mode): every split owns >= 1 real channel; fewer splits than asked for if the channel count does not
+    // allow more; the factor is a function of (c_in, ksplit) only, so a frame's sums do not depend on the launch size
+    p.ksplit = 1; p.cper = p.CinPad; p.part = partial;
+    if (ksplit > 1) {
+        if (!sparse) CSK_FAIL("gcn_stage_splitk: split-K is built for the skeleton-sparse kernel (shared adjacency, <= 1/1/4 non-zeros per column)");
+        p.cper = round_up((p.CinPad + ksplit - 1) / ksplit, 8);
+        p.ksplit = (c_in + p.cper - 1) / p.cper;
+    }
     if (sparse) {
         const int R = p.R;
         size_t lds2;
         void (*k)(GcnParams);
         // ping-pong LDS, trickled loads, 3 workgroups / CU
         lds2 = 2 * (size_t)(R * 8 * MT + 8 * p.ldb) * sizeof(float);
-        k = big ? (R == 4 ? gcn_stage_sparse2_kernel<128, true, 8> : gcn_stage_sparse2_kernel<128, false, 8>)
-                : (R == 4 ? gcn_stage_sparse2_kernel<64, true, 8> : gcn_stage_sparse2_kernel<64, false, 8>);
+        if (p.ksplit > 1) {
+            if ((int64_t)p.qtiles * p.mtiles * n_seg * p.ksplit >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
+            grid = dim3(p.qtiles * p.mtiles * n_seg * p.ksplit);
+            k = big ? (R == 4 ? gcn_stage_sparse2_kernel<128, true, 8, false, true> : gcn_stage_sparse2_kernel<128, false, 8, false, true>)
+                    : (R == 4 ? gcn_stage_sparse2_kernel<64, true, 8, false, true> : gcn_stage_sparse2_kernel<64, false, 8, false, true>);
+        } else {
+            k = big ? (R == 4 ? gcn_stage_sparse2_kernel<128, true, 8> : gcn_stage_sparse2_kernel<128, false, 8>)
+                    : (R == 4 ? gcn_stage_sparse2_kernel<64, true, 8> : gcn_stage_sparse2_kernel<64, false, 8>);
+        }
         const int e = csk_ensure_lds((const void *)k, lds2);
         if (e) return e;
         hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds2, (hipStream_t)stream, p);
+        if (p.ksplit > 1) {
+            if (const int e2 = (int)hipGetLastError()) return e2;
+            const int64_t work = (int64_t)c_out * Q;
+            hipLaunchKernelGGL(gcn_reduce_kernel, dim3((unsigned)((work + 255) / 256), n_seg), dim3(256), 0, (hipStream_t)stream, p);
+        }
         return (int)hipGetLastError();
     }
     // dense per-sample / per-frame adjacency with an even V <= 18: on-the-fly aggregation from register-resident adjacency
@@ -845,6 +886,25 @@ extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
+}
+
+extern "C" int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
+                                 const float *ell_val, const int32_t *ell_cnt, int ell_w, int64_t adj_seg_stride,
+                                 int adj_per_frame,
+                                 int n_seg, int c_in, int c_out, int frames, int V, int64_t x_seg_stride,
+                                 int64_t x_chan_stride, int64_t y_seg_stride, int64_t y_chan_stride, int res_mode,
+                                 void *stream) {
+    return gcn_stage_impl(x, y, w, bias, ell_src, ell_val, ell_cnt, ell_w, adj_seg_stride, adj_per_frame, n_seg, c_in, c_out, frames,
+                          V, x_seg_stride, x_chan_stride, y_seg_stride, y_chan_stride, res_mode, 1, nullptr, stream);
+}
+
+extern "C" int csk_gcn_stage_splitk_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
+                                        const float *ell_val, const int32_t *ell_cnt, int ell_w, int n_seg, int c_in, int c_out,
+                                        int frames, int V, int64_t x_seg_stride, int64_t x_chan_stride, int64_t y_seg_stride,
+                                        int64_t y_chan_stride, int res_mode, int ksplit, float *partial, void *stream) {
+    if (ksplit < 1 || ksplit > 32 || (ksplit > 1 && !partial)) CSK_FAIL("gcn_stage_splitk: ksplit must be in [1, 32] and needs a partial-sum buffer");
+    return gcn_stage_impl(x, y, w, bias, ell_src, ell_val, ell_cnt, ell_w, 0, 0, n_seg, c_in, c_out, frames, V, x_seg_stride,
+                          x_chan_stride, y_seg_stride, y_chan_stride, res_mode, ksplit, partial, stream);
 }
 
 

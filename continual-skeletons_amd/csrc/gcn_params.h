@@ -18,6 +18,10 @@ struct GcnParams {
     int fast_epi;        // channel strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
     int no_pair_reads;   // diagnostic (CSK_NO_PAIR_READS): general kernel aggregates with scalar LDS reads for even V too
     int no_vec;          // diagnostic (CSK_GCN_NOVEC): sparse kernel stages activations element-wise on every tile
+    // split-K (latency mode, csk_gcn_stage_splitk_f32): split ks of a tile covers channels [ks * cper, + cper) and writes raw
+    // partial sums to part[(seg * ksplit + ks)][Cout][y_chan_stride]; gcn_reduce_kernel adds them up in split order
+    int ksplit, cper;
+    float *part;
 };
 
 // gcn_dense.hip: dense (per-segment or per-frame) adjacency with an even joint count V <= 18; returns -2 when the shape is

@@ -592,7 +592,7 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
                                 int c, int c_out, int64_t P, int k, int res_mode, int c_res, int relu, int ksplit,
                                 float *partial, void *stream) {
     if (!ring || !w || !bias || !out) CSK_FAIL("tcn_step: null pointer");
-    if (ksplit < 1 || ksplit > 16 || (ksplit > 1 && !partial)) CSK_FAIL("tcn_step: ksplit must be in [1, 16] and needs a partial-sum buffer");
+    if (ksplit < 1 || ksplit > 32 || (ksplit > 1 && !partial)) CSK_FAIL("tcn_step: ksplit must be in [1, 32] and needs a partial-sum buffer");
     if (c <= 0 || c_out <= 0 || P < 4 || (P & 3)) CSK_FAIL("tcn_step: bad dims (P must be a positive multiple of 4)");
     if (k < 1 || k > 9 || slots < k || head < 0 || head >= slots) CSK_FAIL("tcn_step: bad k/slots/head");
     if (n_emit < 1 || n_emit > 64 || head_step < 0 || out_slots < n_emit || out_slot0 < 0 || out_slot0 >= out_slots)

@@ -18,6 +18,7 @@ SIGNATURES = {
     "csk_abi_version": [],
     "csk_stream_overlap_probe": [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)],
     "csk_gcn_stage_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _p],
+    "csk_gcn_stage_splitk_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _p, _p],
     "csk_tcn_stage_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "csk_conv1x1_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _p],
     "csk_tcn_stage_bf16x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -50,6 +51,7 @@ class CoLayer(C.Structure):
     _fields_ = [("c_in", C.c_int32), ("c_out", C.c_int32), ("stride", C.c_int32), ("res_kind", C.c_int32),
                 ("gcn_res_mode", C.c_int32), ("ell_w", C.c_int32), ("ell_cnt", C.c_int32 * 3), ("tcn_ksplit", C.c_int32),
                 ("y_slots", C.c_int32), ("out_slots", C.c_int32), ("partial_emits", C.c_int32), ("agcn_adj_frames", C.c_int32),
+                ("gcn_ksplit", C.c_int32), ("gcn_partial_frames", C.c_int32),
                 ("gcn_w", C.c_void_p), ("gcn_bias", C.c_void_p), ("ell_src", C.c_void_p), ("ell_val", C.c_void_p),
                 ("tcn_w", C.c_void_p), ("tcn_w_res", C.c_void_p), ("tcn_bias", C.c_void_p),
                 ("y_ring", C.c_void_p), ("out_ring", C.c_void_p), ("tcn_partial", C.c_void_p),

@@ -83,6 +83,19 @@ int csk_gcn_stage_f32(const float *x, float *y, const float *w, const float *bia
                       int res_mode, void *stream);
 
 /*
+ * The same stage with its K loop split over workgroups (latency mode: a handful of streams, where one workgroup per tile
+ * would walk all 3 * c_in / 8 K-chunks alone -- 41 us at c_in = 256): the channel axis is cut into up to ksplit ranges
+ * computed by separate workgroups into `partial` ([n_seg * ksplit][c_out][y_chan_stride] floats) and summed in split
+ * order by a second kernel that also applies bias / identity gcn_residual / ReLU.  Graphs shared by all segments with
+ * <= 1 / 1 / 4 non-zeros per column only (skeleton graphs).  Results differ from csk_gcn_stage_f32 by fp32 summation
+ * order only; for a given ksplit they do not depend on n_seg or frames.  ksplit = 1 is csk_gcn_stage_f32.
+ */
+int csk_gcn_stage_splitk_f32(const float *x, float *y, const float *w, const float *bias, const int32_t *ell_src,
+                             const float *ell_val, const int32_t *ell_cnt, int ell_w, int n_seg, int c_in, int c_out,
+                             int frames, int V, int64_t x_seg_stride, int64_t x_chan_stride, int64_t y_seg_stride,
+                             int64_t y_chan_stride, int res_mode, int ksplit, float *partial, void *stream);
+
+/*
  * TemporalConvolution.forward (models/base.py:302-304) fused with the tail of
  * SpatioTemporalBlock.forward (base.py:376-387):
  *     out = ReLU( BN(conv_{k x 1, stride s, pad p}(y)) + residual(x[:, :, shrink:T-shrink]) )
@@ -302,6 +315,10 @@ typedef struct csk_co_layer {
     int32_t y_slots, out_slots;              /* depths of y_ring / out_ring (see CSK_CO_Y_SLOTS / CSK_CO_IN_SLOTS)  */
     int32_t partial_emits;                   /* emissions the split-K scratch holds (0 when tcn_ksplit == 1)       */
     int32_t agcn_adj_frames;                 /* frames of per-skeleton adjacencies agcn_adj holds (0: no adaptive graph conv) */
+    int32_t gcn_ksplit, gcn_partial_frames;  /* split-K of the graph conv (csk_gcn_stage_splitk_f32, latency mode); <= 1 = off.  Its
+                                              * partial sums go to tcn_partial as well (launches are stream-ordered), which then
+                                              * holds gcn_partial_frames * gcn_ksplit * c_out * P floats: the frames ONE graph-conv
+                                              * launch may cover (more frames in a cycle fail with an error) */
     const float *gcn_w, *gcn_bias;           /* packed operands of csk_gcn_stage_f32                       */
     const int32_t *ell_src;
     const float *ell_val;

@@ -416,6 +416,9 @@ def test_latency_mode_split_k_matches_oracle_and_default(native_plan):
     # default: the 256-channel blocks always split their K loop in 3 (slab-size independent), nothing else is split
     assert [nets["default"].layers[f"layer{i + 1}"]._state.ksplit for i in range(10)] == [1] * 7 + [3] * 3
     assert nets["latency"].layers["layer9"]._state.ksplit > 3 and nets["latency"].layers["layer2"]._state.ksplit > 1
+    # ... and the graph convs split theirs too (csk_gcn_stage_splitk_f32); layer 1 (3 input channels) has nothing to split
+    assert [nets["default"].layers[f"layer{i + 1}"]._state.gcn_ksplit for i in range(10)] == [1] * 10
+    assert nets["latency"].layers["layer1"]._state.gcn_ksplit == 1 and nets["latency"].layers["layer9"]._state.gcn_ksplit >= 8
     for d, l, c in zip(outs["default"], outs["latency"], outs["latency_cycles"]):
         check_parity(l.cpu(), d.cpu(), note="latency mode vs default (summation order)")
         assert torch.equal(l, c)                                # 4-frame cycles: bit-identical to per-frame stepping
@@ -435,6 +438,7 @@ def test_latency_mode_split_k_matches_oracle_and_default(native_plan):
         r0, r1 = big[0].forward_step(frames[t]), big[1].forward_step(frames[t])
         assert (r0 is None) == (r1 is None) and (r0 is None or torch.equal(r0, r1))
     assert all(big[1].layers[f"layer{i + 1}"]._state.ksplit == big[0].layers[f"layer{i + 1}"]._state.ksplit for i in range(10))
+    assert all(big[1].layers[f"layer{i + 1}"]._state.gcn_ksplit == 1 for i in range(10))
 
 
 def _set_fusion(model, on):
