@@ -802,13 +802,14 @@ class CoStGcn(_Folded):
         """Same protocol driven from Python (any graph-conv module with a ``stage`` method)."""
         n, c, v, m = frames[0].shape
         ops = self._packed_ops(frames[0].device)
-        for x_t in frames:
-            dst = self._xin0[self._frames % self._xin0.shape[0]]
-            # reshape1 + data_bn + reshape2 (base.py:73-82) straight into the channel-major input ring
-            rc = native.lib().csk_input_norm_f32(native.ptr(x_t), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
-                                                 native.ptr(dst), n, c, 1, v, m, v, self._p, native.stream_of(x_t))
-            native.check(rc, "csk_input_norm_f32")
-            self._frames += 1
+        # reshape1 + data_bn + reshape2 (base.py:73-82) of the cycle's frames straight into the channel-major input ring
+        depth = self._xin0.shape[0]
+        srcs = (ctypes.c_void_p * len(frames))(*[x_t.data_ptr() for x_t in frames])
+        dsts = (ctypes.c_void_p * len(frames))(*[self._xin0[(self._frames + f) % depth].data_ptr() for f in range(len(frames))])
+        rc = native.lib().csk_input_norm_frames_f32(srcs, dsts, len(frames), native.ptr(ops["scale"]), native.ptr(ops["shift"]),
+                                                    n, c, v, m, self._p, native.stream_of(frames[0]))
+        native.check(rc, "csk_input_norm_frames_f32")
+        self._frames += len(frames)
         r, res = len(frames), None
         for i in range(10):
             res = self.layers[f"layer{i + 1}"].engine_advance(r, n * m, v)
@@ -829,21 +830,15 @@ class CoStGcn(_Folded):
         lib = native.lib()
         head = self._feats % self.pool_size
         stream = native.stream_of(st10.out)
-        if slot is None:                           # end padding of the pooling window: a zero feature
-            self._pool_ring[head].zero_()
-        else:
-            native.check(lib.csk_co_spatial_pool_f32(native.ptr(st10.out[slot]), native.ptr(self._pool_ring[head]), n, 256,
-                                                     m * v, self._p, stream), "csk_co_spatial_pool_f32")
         self._feats += 1
-        if self._feats < self.pool_size - self.pool_padding:
-            return None
+        emit = self._feats >= self.pool_size - self.pool_padding
         count = min(self._feats, self.pool_size)
-        native.check(lib.csk_co_window_mean_f32(native.ptr(self._pool_ring), native.ptr(self._pooled), n * 256,
-                                                self.pool_size, head, count, stream), "csk_co_window_mean_f32")
-        logits = torch.empty((n, self.num_classes), device=st10.out.device, dtype=torch.float32)
-        native.check(lib.csk_fc_f32(native.ptr(self._pooled), native.ptr(self.fc.weight.detach()),
-                                    native.ptr(self.fc.bias.detach()), native.ptr(logits), n, 256, self.num_classes,
-                                    stream), "csk_fc_f32")
+        logits = torch.empty((n, self.num_classes), device=st10.out.device, dtype=torch.float32) if emit else None
+        # slot None: end padding of the pooling window (a zero feature enters it)
+        native.check(lib.csk_co_head_step_f32(
+            native.ptr(st10.out[slot]) if slot is not None else None, native.ptr(self._pool_ring), native.ptr(self._pooled),
+            native.ptr(self.fc.weight.detach()), native.ptr(self.fc.bias.detach()), native.ptr(logits), n, 256, m * v, self._p,
+            self.pool_size, head, count, int(emit), self.num_classes, stream), "csk_co_head_step_f32")
         return logits
 
     def features_step(self, x_t):

@@ -243,13 +243,14 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
         csk_co_plan *p; long frames, feats; std::vector<BlockCounters> cnt; bool armed = true;
         ~Rollback() { if (armed) { p->frames = frames; p->feats = feats; p->cnt = cnt; } }
     } rollback{p, p->frames, p->feats, p->cnt};
-    for (int f = 0; f < r; ++f) {                  // reshape1 + data_bn + reshape2 into the channel-major ring
-        if (!frames[f]) CSK_FAIL("co_plan_cycle: null frame");
-        float *dst = p->xin0 + (p->frames % p->xin0_slots) * (int64_t)p->C * p->P;
-        const int rc = csk_input_norm_f32(frames[f], p->bn_scale, p->bn_shift, dst, p->N, p->C, 1, p->V, p->M, p->V, p->P,
-                                          stream);
-        if (rc) return rc;
-        p->frames++;
+    {   // reshape1 + data_bn + reshape2 of the cycle's frames into the channel-major ring: one launch
+        float *dst[CSK_CO_MAX_CYCLE];
+        for (int f = 0; f < r; ++f) {
+            if (!frames[f]) CSK_FAIL("co_plan_cycle: null frame");
+            dst[f] = p->xin0 + ((p->frames + f) % p->xin0_slots) * (int64_t)p->C * p->P;
+        }
+        if (const int rc = csk_input_norm_frames_f32(frames, dst, r, p->bn_scale, p->bn_shift, p->N, p->C, p->V, p->M, p->P, stream)) return rc;
+        p->frames += r;
     }
     int rr = 0, slot0 = 0;
     if (const int rc = run_blocks(p, r, &slot0, &rr, stream)) return rc;
@@ -258,21 +259,17 @@ extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int
     *n_feat = rr;
     const csk_co_layer &last = p->layers.back();
     const int64_t n_elem = (int64_t)p->N * last.c_out;
-    for (int j = 0; j < rr; ++j) {                 // spatial_pool -> co.AvgPool1d window -> co.Linear
+    for (int j = 0; j < rr; ++j) {                 // spatial_pool -> co.AvgPool1d window -> co.Linear: one launch per emission
         const int slot = (slot0 + j) % last.out_slots;
         const int head = (int)(p->feats % p->pool_size);
-        int rc = csk_co_spatial_pool_f32(last.out_ring + slot * (int64_t)last.c_out * p->P, p->pool_ring + head * n_elem,
-                                         p->N, last.c_out, p->M * p->V, p->P, stream);
-        if (rc) return rc;
         p->feats++;
-        if (p->feats < p->pool_size - p->pool_padding) continue;
+        const int emit = p->feats >= p->pool_size - p->pool_padding;
         const int count = (int)(p->feats < p->pool_size ? p->feats : p->pool_size);
-        rc = csk_co_window_mean_f32(p->pool_ring, p->pooled, n_elem, p->pool_size, head, count, stream);
+        const int rc = csk_co_head_step_f32(last.out_ring + slot * (int64_t)last.c_out * p->P, p->pool_ring, p->pooled, p->fc_w, p->fc_b,
+                                            logits + (int64_t)(*n_logits) * p->N * p->classes, p->N, last.c_out, p->M * p->V, p->P,
+                                            p->pool_size, head, count, emit, p->classes, stream);
         if (rc) return rc;
-        rc = csk_fc_f32(p->pooled, p->fc_w, p->fc_b, logits + (int64_t)(*n_logits) * p->N * p->classes, p->N,
-                        last.c_out, p->classes, stream);
-        if (rc) return rc;
-        (*n_logits)++;
+        if (emit) (*n_logits)++;
     }
     rollback.armed = false;
     return 0;

@@ -33,6 +33,8 @@ SIGNATURES = {
     "csk_co_block_step_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _l, _p],
     "csk_co_spatial_pool_f32": [_p, _p, _i, _i, _i, _l, _p],
     "csk_co_window_mean_f32": [_p, _p, _l, _i, _i, _i, _p],
+    "csk_co_head_step_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _i, _i, _i, _i, _i, _p],
+    "csk_input_norm_frames_f32": [_p, _p, _i, _p, _p, _i, _i, _i, _i, _l, _p],
 
     "csk_fuse_rank_f32": [_p, _i, _i, _i, _i, _l, _l, _p, _p, _p, _p],
     "csk_co_plan_create": [_i, _p, _p, _i, _i, _i, _i, _i, _l, _p, _p, _i, _p, _p, _i, _i, _p, _p],

@@ -279,6 +279,18 @@ int csk_co_spatial_pool_f32(const float *h, float *feat, int N, int C, int MV, i
 int csk_co_window_mean_f32(const float *ring, float *pooled, int64_t n_elem, int window, int head, int count,
                            void *stream);
 
+/* The three steps above and csk_fc_f32 in ONE launch (one workgroup per stream), bit-identical to issuing them one by one:
+ * spatial_pool of frame h (NULL: a zero feature, the window's end padding) into pool_ring[head], then -- when `emit` --
+ * pooled = window mean of the `count` newest entries and logits = pooled @ fc_w^T + fc_b.  pool_ring [window][N][C],
+ * pooled [N][C], logits [N][classes]; fc_w 16-byte aligned when C % 4 == 0. */
+int csk_co_head_step_f32(const float *h, float *pool_ring, float *pooled, const float *fc_w, const float *fc_b, float *logits,
+                         int N, int C, int MV, int64_t P, int window, int head, int count, int emit, int classes, void *stream);
+
+/* csk_input_norm_f32 for the r = 1..8 frames of a launch cycle in one launch (continual form, T = 1): frames[f] (N, C, V, M)
+ * -> dst[f] channel-major (C, P) (models/base.py:73-82).  frames / dst are HOST arrays of device pointers. */
+int csk_input_norm_frames_f32(const float *const *frames, float *const *dst, int r, const float *scale, const float *shift,
+                              int N, int C, int V, int M, int64_t P, void *stream);
+
 /*
  * Multi-stream logit fusion + top-k support, scripts/multi_stream_eval.py:33-60: fused = left fold of add
  * (use_max = 0) or maximum (1) over n_streams <= 4 prediction arrays (host array of device pointers); element
