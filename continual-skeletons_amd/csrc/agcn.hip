@@ -3,6 +3,15 @@
 
 #include "mfma_core.h"
 
+// Softmax arithmetic shared by every attention kernel of this file (so that the fused and the two-launch routes, and the
+// per-frame and per-segment forms, keep producing the same bits): the exponential through the hardware v_exp_f32 (a multiply
+// by log2 e in front; arguments are <= 0, relative error of the result <= |x| * 2^-23 -- 1e-6 at x = -10) and ONE IEEE
+// division per column (reciprocal of the column sum) instead of one per element.  With libm's expf and per-element IEEE
+// divisions the softmax was ~3 k of the ~4 k cycles a wave spent on one (pair, skeleton) attention unit of the fused
+// step kernel (16 exponentials + 16 divisions of ~10-15 instructions each per lane): profiles/HISTORY.md round 4.
+__device__ __forceinline__ float sm_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float sm_rcp(float sum) { return 1.f / sum; }
+
 // ------------------------------------------------------------------------------------------------
 // A-GCN attention (models/a_gcn/a_gcn.py:53-63): per sample n and subset i
 //     logits[v, w] = sum_{k,t} Ea[i][k][t][v] * Eb[i][k][t][w] / (inter * T)
@@ -112,9 +121,10 @@ __global__ __launch_bounds__(256) void agcn_softmax_kernel(const float *__restri
         m = fmaxf(m, lg[v]);
     }
     float sum = 0.f;
-    for (int v = 0; v < V; ++v) sum += expf(lg[v] - m);
+    for (int v = 0; v < V; ++v) sum += sm_exp(lg[v] - m);
     float *dst = ell_val + ((int64_t)pair * V + w) * V;
-    for (int v = 0; v < V; ++v) dst[v] = expf(lg[v] - m) / sum + a_sum[(i * V + v) * V + w];
+    const float rs = sm_rcp(sum);
+    for (int v = 0; v < V; ++v) dst[v] = sm_exp(lg[v] - m) * rs + a_sum[(i * V + v) * V + w];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -165,17 +175,18 @@ __global__ __launch_bounds__(256) void agcn_attention_step_kernel(const float *_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int v = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        acc[r] = v < V ? expf(acc[r] - m) : 0.f;
+        acc[r] = v < V ? sm_exp(acc[r] - m) : 0.f;
         sum += acc[r];
     }
     sum += __shfl_xor(sum, 32);
+    const float rs = sm_rcp(sum);
     if (col) {
         float *dst = ell_val + ((int64_t)(n * 3 + i) * V + l31) * V;            // [n][i][w][v]
         const float *as = a_sum + (int64_t)i * V * V + l31;                       // [i][v][w]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int v = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (v < V) dst[v] = acc[r] / sum + as[v * V];
+            if (v < V) dst[v] = acc[r] * rs + as[v * V];
         }
     }
 }
@@ -394,10 +405,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int v = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            lg[r] = v < V ? expf(lg[r] - m) : 0.f;
+            lg[r] = v < V ? sm_exp(lg[r] - m) : 0.f;
             sum += lg[r];
         }
         sum += __shfl_xor(sum, 32);
+        const float rs = sm_rcp(sum);
         if (col) {
             const int pi = mt * NP + pr;
             const int64_t n = (int64_t)seg * p.frames + ta + f;
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void agcn_embed_attention_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int v = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (v < V) dst[v] = lg[r] / sum + as[v * V];
+                if (v < V) dst[v] = lg[r] * rs + as[v * V];
             }
         }
     }
@@ -431,9 +443,10 @@ __global__ __launch_bounds__(NTHREADS) void agcn_softmax_parts_kernel(const floa
         float m = -INFINITY;
         for (int v = 0; v < V; ++v) m = fmaxf(m, lg[v * 33 + w]);
         float sum = 0.f;
-        for (int v = 0; v < V; ++v) sum += expf(lg[v * 33 + w] - m);
+        for (int v = 0; v < V; ++v) sum += sm_exp(lg[v * 33 + w] - m);
+        const float rs = sm_rcp(sum);
         float *dst = ell_val + ((int64_t)pair * V + w) * V;
-        for (int v = 0; v < V; ++v) dst[v] = expf(lg[v * 33 + w] - m) / sum + a_sum[(i * V + v) * V + w];
+        for (int v = 0; v < V; ++v) dst[v] = sm_exp(lg[v * 33 + w] - m) * rs + a_sum[(i * V + v) * V + w];
     }
 }
 

@@ -123,10 +123,19 @@ __global__ __launch_bounds__(256) void co_head_kernel(const float *__restrict__ 
     for (int c = tid; c < Cp; c += 256) {
         float s = 0.f;
         if (c < C) {
-            for (int j = count - 1; j >= 1; --j) {
-                int slot = (head - j) % window;
-                if (slot < 0) slot += window;
-                s += ring[(int64_t)slot * n_elem + (int64_t)n * C + c];
+            // eight ring entries in flight per thread (a rolled loop waits for every load: 75 dependent round trips);
+            // the additions stay in oldest-first order
+            for (int j0 = count - 1; j0 >= 1; j0 -= 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int slot = (head - max(j0 - u, 1)) % window;
+                    if (slot < 0) slot += window;
+                    v[u] = ring[(int64_t)slot * n_elem + (int64_t)n * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 - u >= 1) s += v[u];
             }
             if (count >= 1) s += feat_s[c];
             s = s / (float)window;

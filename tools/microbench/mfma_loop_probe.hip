@@ -383,100 +383,9 @@ double run_aglobal(int chunks, int blocks, size_t lds_extra = 0) {
 }
 
 
-// GLDS variant: the weights are staged by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write) in ping-pong 3-tap stages
-// (2 x 12 KB), one barrier per stage; the activation tile keeps the register path (18 loads + 18 LDS writes per thread and
-// chunk) but double-buffered, committed beside the last stage's MFMAs: three barriers per chunk, no commit phase.
-typedef __attribute__((address_space(3))) void lds_void;
-template <int OCC, bool BGLDS = false>
-__global__ __launch_bounds__(256, OCC) void glds_kernel(float *out, const float *gw, const float *gb, int chunks) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WST = 3 * KC * MT;                       // floats per 3-tap weight stage
-    float *Ws = smem, *Bs = smem + 2 * WST;                // Ws[2][WST], Bs[2][KC * LDB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, kh = lane >> 5;
-    for (int i = tid; i < 2 * WST + 2 * KC * LDB; i += 256) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
-    __syncthreads();
-    const int offA = (wave & 1) * 64 + l31, off0 = (wave >> 1) * 64 + l31, off1 = off0 + 32;
-    f32x16 acc[2][2];
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
-    float bv[18];
-    for (int u = 0; u < 18; ++u) bv[u] = gb[(size_t)blockIdx.x * 65536 + u * 256 + tid];
-    // one stage = 12 KB = 12 wave-instructions of 1 KB: three per wave
-    auto glds_stage = [&](float *dst, const float *src) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int blk = wave * 3 + i;                  // 1 KB block of the stage (wave-uniform)
-            __builtin_amdgcn_global_load_lds(src + blk * 256 + lane * 4, (lds_void *)(dst + blk * 256), 16, 0, 0);
-        }
-    };
-    glds_stage(Ws, gw);
-    __syncthreads();
-    int st = 0;
-    for (int c = 0; c < chunks; ++c) {
-        const float *gwc = gw + (size_t)(c & 31) * 9216, *gwn = gw + (size_t)((c + 1) & 31) * 9216;
-        const float *gbc = gb + (size_t)blockIdx.x * 65536 + (size_t)((c + 1) & 7) * 4608;
-        float *Bc = Bs + (c & 1) * KC * LDB, *Bn = Bs + ((c + 1) & 1) * KC * LDB;
-#pragma unroll
-        for (int g3 = 0; g3 < 3; ++g3) {
-            // next stage's weights straight into the other LDS stage (its last readers passed the previous barrier)
-            glds_stage(Ws + ((st + 1) & 1) * WST, g3 < 2 ? gwc + (g3 + 1) * WST : gwn);
-            if (BGLDS) {
-                // the activation tile by LDS-DMA too (as if its rows were lane-linear 1 KB pieces): 12 KB = 3 instructions per wave
-                if (g3 == 0) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const int blk = wave * 3 + i;
-                        __builtin_amdgcn_global_load_lds(gbc + blk * 256 + lane * 4, (lds_void *)(Bn + blk * 256), 16, 0, 0);
-                    }
-                }
-            } else {
-                if (g3 == 0) {
-#pragma unroll
-                    for (int u = 0; u < 18; ++u) bv[u] = gbc[u * 256 + tid];
-                }
-                if (g3 == 2) {
-#pragma unroll
-                    for (int u = 0; u < 18; ++u) Bn[(u >> 1) % KC * LDB + (u & 1) * 128 + (tid & 127)] = bv[u] + (float)(tid >> 7);
-                }
-            }
-            const float *Wc = Ws + (st & 1) * WST;
-            for (int r = 0; r < 3; ++r) {
-                const float *wr = Wc + r * (KC * MT) + offA + kh * MT, *br = Bc + (3 * g3 + r) * 25 + kh * LDB;
-#pragma unroll
-                for (int s = 0; s < KC / 2; ++s) {
-                    const float a0 = wr[2*s*MT], a1 = wr[2*s*MT+32], b0 = br[2*s*LDB+off0], b1 = br[2*s*LDB+off1];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-            ++st;
-        }
-    }
-    float s = 0.f;
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int g = 0; g < 16; ++g) s += acc[a][b][g];
-    for (int u = 0; u < 18; ++u) s += bv[u];
-    out[blockIdx.x * 256 + tid] = s;
-}
-
-template <int OCC, bool BGLDS = false> double run_glds(int chunks, int blocks, size_t lds_extra = 0) {
-    float *out, *gw, *gb;
-    hipMalloc(&out, (size_t)blocks * 256 * 4);
-    hipMalloc(&gw, (size_t)34 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)34 * 9216 * 4 + 65536);
-    hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
-    const size_t lds = (size_t)(2 * 3 * KC * MT + 2 * KC * LDB) * 4 + lds_extra;
-    hipFuncSetAttribute((const void *)glds_kernel<OCC, BGLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((glds_kernel<OCC, BGLDS>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
-    hipEventRecord(e0);
-    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((glds_kernel<OCC, BGLDS>), dim3(blocks), dim3(256), lds, 0, out, gw, gb, chunks);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-    hipFree(out); hipFree(gw); hipFree(gb);
-    const double flops = (double)blocks * 4 * chunks * TAPS * (KC / 2) * 4 * 4096.0;
-    return flops / (ms * 1e-3) / 1e12;
-}
+// (Round 3 priced LDS-DMA staging here -- weights by global_load_lds_dwordx4 in ping-pong 3-tap stages: 136.5 / 137.1 TFLOP/s at
+// 2 / 3 workgroups per CU against 138.5 for the shipped structure; with the activation tile by LDS-DMA as well 143.4 / 144.1.
+// The variants were removed in round 4 together with the decision not to build that staging path: profiles/HISTORY.md.)
 
 
 // STRUCT8: the level-3 structure with EIGHT waves on a 128 x 256 tile (one workgroup per CU, two waves per SIMD from the SAME
@@ -612,12 +521,7 @@ int main() {
     printf("struct 0 at 3 workgroups/CU:                            %.1f TFLOP/s\n", run_struct<0, 3>(chunks, 768 * 4));
     printf("struct 3 at 3 workgroups/CU:                            %.1f TFLOP/s\n", run_struct<3, 3>(chunks, 768 * 4));
     printf("struct 3 at 2 workgroups/CU, same grid:                 %.1f TFLOP/s\n", run_struct<3, 2>(chunks, 768 * 4));
-    // weights by LDS-DMA in ping-pong 3-tap stages, activation tile double-buffered through registers, 3 barriers per chunk
-    printf("glds W stages, 2 workgroups/CU:                         %.1f TFLOP/s\n", run_glds<2>(chunks, blocks, 20 * 1024));
-    printf("glds W stages, 3 workgroups/CU:                         %.1f TFLOP/s\n", run_glds<3>(chunks, 768 * 4));
-    printf("glds W stages + glds activation tile, 2 / 3 workgroups/CU: %.1f / %.1f TFLOP/s\n", run_glds<2, true>(chunks, blocks, 20 * 1024), run_glds<3, true>(chunks, 768 * 4));
     printf("8 waves, 128 x 256 tile, 1 workgroup/CU: struct 0 / 1 / 2 / 3: %.1f / %.1f / %.1f / %.1f TFLOP/s\n", run_struct8<0>(chunks, 256 * 6),
            run_struct8<1>(chunks, 256 * 6), run_struct8<2>(chunks, 256 * 6), run_struct8<3>(chunks, 256 * 6));
-    printf("glds W stages, 1 workgroup/CU:                          %.1f TFLOP/s\n", run_glds<2>(chunks, 256 * 6, 64 * 1024));
     return 0;
 }

@@ -1,11 +1,13 @@
 #!/usr/bin/env bash
-# Run ON THE GPU BOX (via gpurun): every rocprofv3 pass behind the round-3 profile summaries.
+# Run ON THE GPU BOX (via gpurun): every rocprofv3 pass behind the round-4 profile summaries.
 #   kernel traces: clip forward (exact fp32 and the opt-in bf16x3 mode), online path (1 and 2 stream shards), config 4
+#               few-stream latency path (1 and 16 streams, one frame per call, latency mode)
 #   PMC passes (separate runs, --kernel-trace only beside --pmc): MFMA busy / wave cycles and FETCH / WRITE bytes of the
-#   clip forward in both precision modes
-# usage: bash tools/profile_r03.sh <tag>
+#   clip forward in both precision modes, of the A-GCN clip forward, and of the ONLINE shapes (tools/online_pass.py
+#   --shards 1, CoST-GCN and CoAGCN: tcn_step / co_block / step-shape GCN / attention launches)
+# usage: bash tools/profile_r04.sh <tag>
 set -uo pipefail
-tag="${1:-r03}"
+tag="${1:-r04}"
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out="$R/gpurun_out/prof_$tag"
 mkdir -p "$out"
@@ -24,6 +26,10 @@ for sh in 1 2 3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/coagcn$sh" -- python3 "$R/tools/online_pass.py" --model coagcn --shards $sh --cycles 16 > "$out/coagcn$sh.log" 2>&1
   grep ONLINE_PASS "$out/coagcn$sh.log"
 done
+for st in 1 16; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/latency$st" -- python3 "$R/tools/latency_pass.py" --streams $st > "$out/latency$st.log" 2>&1
+  grep "ms per frame" "$out/latency$st.log"
+done
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
 for prec in f32 bf16x3; do
   rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$out/sq_$prec" -- python3 "$R/tools/clip_pass.py" --precision $prec --forwards 2 > "$out/sq_$prec.log" 2>&1
@@ -33,5 +39,11 @@ done
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$out/sq_agcn" -- python3 "$R/tools/agcn_prof.py" 64 3 > "$out/sq_agcn.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch_agcn" -- python3 "$R/tools/agcn_prof.py" 64 3 > "$out/fetch_agcn.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write_agcn" -- python3 "$R/tools/agcn_prof.py" 64 3 > "$out/write_agcn.log" 2>&1
+for model in costgcn coagcn; do
+  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$out/sq_online_$model" -- python3 "$R/tools/online_pass.py" --model $model --shards 1 --cycles 8 --warm-cycles 60 > "$out/sq_online_$model.log" 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch_online_$model" -- python3 "$R/tools/online_pass.py" --model $model --shards 1 --cycles 8 --warm-cycles 60 > "$out/fetch_online_$model.log" 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write_online_$model" -- python3 "$R/tools/online_pass.py" --model $model --shards 1 --cycles 8 --warm-cycles 60 > "$out/write_online_$model.log" 2>&1
+done
 find "$out" -name "*agent_info.csv" -delete
+find "$out" -name "*kernel_trace.csv" -path "*sq_*" -delete; find "$out" -name "*kernel_trace.csv" -path "*fetch_*" -delete; find "$out" -name "*kernel_trace.csv" -path "*write_*" -delete
 du -sh "$out"

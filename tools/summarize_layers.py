@@ -24,7 +24,7 @@ import workmodel as wm  # noqa: E402
 
 def short(name):
     for k in ("gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
-              "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
+              "input_norm_frames_kernel", "co_head_kernel", "gcn_reduce_kernel", "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
               "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel", "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "gcn_stage_dense_kernel", "gcn_stage_dense2_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
@@ -103,7 +103,7 @@ def main():
         # window of the kept cycles: from the first input_norm to the end of the last PATH kernel of the last cycle (what
         # the workload script launches after its timed loop -- isfinite checks, lazily loaded torch kernels -- is not part)
         path = [r for r in good[-1] if klass(r["Kernel_Name"]) != "o" or any(
-            k in r["Kernel_Name"] for k in ("co_spatial_pool", "co_window_mean", "fc_kernel", "pool_kernel"))]
+            k in r["Kernel_Name"] for k in ("co_spatial_pool", "co_window_mean", "fc_kernel", "pool_kernel", "co_head"))]
         windows.append((int(good[0][0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in path)))
         for c in good:
             li, tot, oth, seen_a = 0, 0.0, 0.0, False

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Condense the PMC passes of tools/profile_r03.sh (gpurun_out/prof_<tag>/{sq,fetch,write}_<mode>) into
+"""Condense the PMC passes of tools/profile_r04.sh (gpurun_out/prof_<tag>/{sq,fetch,write}_<mode>) into
 profiles/<out>_pmc_summary.md: per kernel instantiation and precision mode -- launches, clock, MFMA-pipe busy fraction,
 waves per SIMD, wait fractions, HBM read / write MB per launch (FETCH_SIZE calibrated on input_norm_kernel, whose bytes
-are known: MI355X_MICROARCH.md HBM section) -- and refresh profiles/traffic_tcn_stage.json (what bench.py prints as
-roofline.traffic) from the exact-fp32 pass.
+are known: MI355X_MICROARCH.md HBM section) -- and refresh profiles/traffic_tcn_stage.json and traffic_tcn_step.json (what
+bench.py prints as roofline.traffic for the clip / online legs) from the exact-fp32 clip pass and the CoST-GCN online pass.
 usage: python tools/summarize_pmc.py <tag> [out_tag]"""
 import collections
 import csv
@@ -22,7 +22,7 @@ def rows_of(pattern):
 
 def short(name):
     for k in ("tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
-              "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel",
+              "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel", "tcn_step_kernel", "co_block_kernel", "step_reduce_kernel", "co_head_kernel",
               "agcn_logits_partial_kernel", "agcn_softmax_kernel", "input_norm_kernel", "pool_kernel", "fc_kernel"):
         if k in name:
             t = name[name.find("<"): name.find(">") + 1] if "<" in name else ""
@@ -48,10 +48,13 @@ def pmc(d, sub):
 
 def main(tag, out_tag):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    L = [f"# PMC passes ({out_tag}): tools/profile_r03.sh -- `rocprofv3 --kernel-trace --pmc ...` of tools/clip_pass.py (batch 256, both precision "
-         "modes) and tools/agcn_prof.py (A-GCN, Kinetics shape, batch 64); separate passes for SQ counters, FETCH_SIZE and WRITE_SIZE", ""]
+    L = [f"# PMC passes ({out_tag}): tools/profile_r04.sh -- `rocprofv3 --kernel-trace --pmc ...` of tools/clip_pass.py (batch 256, both precision "
+         "modes), tools/agcn_prof.py (A-GCN, Kinetics shape, batch 64) and tools/online_pass.py --shards 1 (the online shapes: CoST-GCN and "
+         "CoAGCN, 1024 streams, 4-frame cycles); separate passes for SQ counters, FETCH_SIZE and WRITE_SIZE", ""]
     for mode, title in (("f32", "ST-GCN clip forward, exact fp32"), ("bf16x3", "ST-GCN clip forward, opt-in bf16x3 temporal conv"),
-                        ("agcn", "A-GCN clip forward (config 4)")):
+                        ("agcn", "A-GCN clip forward (config 4)"),
+                        ("online_costgcn", "online: CoST-GCN, 1024 streams, one stream shard, 4 frames per launch (configs[2] launch shapes)"),
+                        ("online_coagcn", "online: CoAGCN, Kinetics shape, 1024 streams, one stream shard, 4 frames per launch (configs[3])")):
         sq, dur = pmc(d, f"sq_{mode}")
         fetch, _ = pmc(d, f"fetch_{mode}")
         write, _ = pmc(d, f"write_{mode}")
@@ -59,8 +62,8 @@ def main(tag, out_tag):
             continue
         known = 256 * 3 * 300 * 25 * 2 * 4
         cal_raw = fetch.get("input_norm_kernel", {}).get("FETCH_SIZE", [])
-        cal = known / (max(cal_raw) * 1024) if cal_raw and mode != "agcn" else 2.0
-        L += [f"## {title}", "", f"(FETCH_SIZE calibration on input_norm_kernel, {known / 1e6:.2f} MB known: factor {cal:.3f})" if mode != "agcn" else
+        cal = known / (max(cal_raw) * 1024) if cal_raw and mode in ("f32", "bf16x3") else 2.0
+        L += [f"## {title}", "", f"(FETCH_SIZE calibration on input_norm_kernel, {known / 1e6:.2f} MB known: factor {cal:.3f})" if mode in ("f32", "bf16x3") else
               "(FETCH_SIZE x 2: the gfx950 correction of MI355X_MICROARCH.md, as calibrated in the ST-GCN passes)", "",
               "| kernel | launches | avg ms | clock GHz | MFMA busy | waves/SIMD | WAIT_ANY/wave | WAIT_INST/wave | HBM read MB | HBM write MB |",
               "|---|---|---|---|---|---|---|---|---|---|"]
@@ -68,7 +71,7 @@ def main(tag, out_tag):
         for k in sorted(sq, key=lambda kk: -sum(dur[kk])):
             c = sq[k]
             g = sum(c.get("GRBM_GUI_ACTIVE", [0])) / 8
-            if g == 0 or ("stage" not in k and "agcn" not in k):
+            if g == 0 or ("stage" not in k and "agcn" not in k and not (mode.startswith("online") and ("step" in k or "co_" in k))):
                 continue
             wc = sum(c["SQ_WAVE_CYCLES"])
             secs = sum(dur[k]) / 1e3
@@ -80,6 +83,18 @@ def main(tag, out_tag):
             L.append(f"| {k} | {len(dur[k])} | {sum(dur[k]) / len(dur[k]):.4f} | {g / secs / 1e9:.2f} | {sum(c['SQ_VALU_MFMA_BUSY_CYCLES']) / (g * 1024):.3f} | "
                      f"{wc * 4 / (g * 1024):.2f} | {sum(c['SQ_WAIT_ANY']) / wc:.3f} | {sum(c['SQ_WAIT_INST_ANY']) / wc:.3f} | {rd:.1f} | {wr:.1f} |")
         L.append("")
+        if mode == "online_costgcn":
+            dom = [v for k, v in traffic.items() if k.startswith("tcn_step_kernel")]
+            red = traffic.get("step_reduce_kernel")
+            if dom and all(v["read_MB"] == v["read_MB"] for v in dom):
+                n = sum(v["launches"] for v in dom)
+                tot = sum((v["read_MB"] + v["write_MB"]) * 1e6 * v["launches"] for v in dom)
+                if red and red["read_MB"] == red["read_MB"]:
+                    tot += (red["read_MB"] + red["write_MB"]) * 1e6 * red["launches"]      # the split-K launches' reduction
+                json.dump({"kernel": "tcn_step_kernel", "hbm_bytes_per_launch": tot / n, "launches": n, "source": f"profiles/{out_tag}_pmc_summary.md",
+                           "streams": 1024, "stream_shards": 1, "frames_per_launch": 4,
+                           "note": "average over the tcn_step_kernel launches of blocks 5-10 (split-K launches include their step_reduce_kernel)"},
+                          open(os.path.join(ROOT, "profiles", "traffic_tcn_step.json"), "w"), indent=1)
         if mode == "f32":
             dom = [v for k, v in traffic.items() if k.startswith("tcn_stage_kernel")]
             if dom and all(v["read_MB"] == v["read_MB"] for v in dom):
