@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 recs = [json.loads(ln) for ln in open(src) if ln.strip()]
 modes = collections.defaultdict(list)
 for r in recs:
