@@ -90,10 +90,11 @@ __global__ __launch_bounds__(256) void co_head_kernel(const float *__restrict__ 
     const int64_t n_elem = (int64_t)N * C;
     if (h) {
         const float *src0 = h + (int64_t)n * MV;
-        for (int c0 = wave; c0 < C; c0 += 32) {                             // 8 rows of this wave in flight
-            float s[8];
+        constexpr int RF = 16;                                              // rows of this wave in flight
+        for (int c0 = wave; c0 < C; c0 += 4 * RF) {
+            float s[RF];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RF; ++u) {
                 const int c = min(c0 + 4 * u, C - 1);
                 const float *src = src0 + (int64_t)c * P;
                 float a = 0.f;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void co_head_kernel(const float *__restrict__ 
                 s[u] = a;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RF; ++u) {
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
                 const int c = c0 + 4 * u;
@@ -144,20 +145,26 @@ __global__ __launch_bounds__(256) void co_head_kernel(const float *__restrict__ 
         pool_s[c] = s;
     }
     __syncthreads();
-    for (int k = tid; k < classes; k += 256) {
-        const float *wr = w + (int64_t)k * C;
-        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-        int c = 0;
-        if ((C & 3) == 0) {
-            for (; c < C; c += 4) {
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + c);
-                const f32x4 fv = *reinterpret_cast<const f32x4 *>(pool_s + c);
+    // FC: fc_kernel's four interleaved chains (channel c goes to chain c mod 4, combined as (s0 + s1) + (s2 + s3)), one chain
+    // per THREAD here -- four neighbouring lanes share a class -- so that 256 threads work on 64 classes at a time instead of
+    // 60 threads walking 256 channels each (one stream: a single workgroup does the whole head).  Same sums, same order.
+    const int chain = tid & 3;
+    for (int k0 = 0; k0 < classes; k0 += 64) {
+        const int k = k0 + (tid >> 2);
+        const float *wr = w + (int64_t)min(k, classes - 1) * C;
+        float sc = 0.f;
+        int c = chain;
+        for (; c + 28 < C; c += 32) {                       // eight weight loads in flight
+            float wv[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s4[i] = fmaf(fv[i], wv[i], s4[i]);
-            }
+            for (int u = 0; u < 8; ++u) wv[u] = wr[c + 4 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sc = fmaf(pool_s[c + 4 * u], wv[u], sc);
         }
-        for (; c < C; ++c) s4[c & 3] = fmaf(pool_s[c], wr[c], s4[c & 3]);
-        logits[(int64_t)n * classes + k] = ((s4[0] + s4[1]) + (s4[2] + s4[3])) + b[k];
+        for (; c < C; c += 4) sc = fmaf(pool_s[c], wr[c], sc);
+        sc += __shfl_xor(sc, 1);                            // lanes 0 / 2 of a quad: s0 + s1, s2 + s3
+        sc += __shfl_xor(sc, 2);                            // (s0 + s1) + (s2 + s3)
+        if (chain == 0 && k < classes) logits[(int64_t)n * classes + k] = sc + b[k];
     }
 }
 
@@ -169,7 +176,6 @@ extern "C" int csk_co_head_step_f32(const float *h, float *pool_ring, float *poo
         count > window)
         CSK_FAIL("co_head_step: bad dims");
     if (emit && (!pooled || !fc_w || !fc_b || !logits || classes <= 0 || count < 1)) CSK_FAIL("co_head_step: an emitting step needs pooled, fc_w, fc_b, logits and count >= 1");
-    if (emit && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(fc_w) & 15)) CSK_FAIL("co_head_step: fc_w must be 16-byte aligned when C is a multiple of 4");
     const size_t lds = 2 * (size_t)((C + 3) & ~3) * sizeof(float);
     hipLaunchKernelGGL(co_head_kernel, dim3((unsigned)N), dim3(256), lds, (hipStream_t)stream, h, pool_ring, pooled, fc_w, fc_b, logits, N,
                        C, MV, P, window, head, count, emit, classes);

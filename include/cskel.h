@@ -282,7 +282,7 @@ int csk_co_window_mean_f32(const float *ring, float *pooled, int64_t n_elem, int
 /* The three steps above and csk_fc_f32 in ONE launch (one workgroup per stream), bit-identical to issuing them one by one:
  * spatial_pool of frame h (NULL: a zero feature, the window's end padding) into pool_ring[head], then -- when `emit` --
  * pooled = window mean of the `count` newest entries and logits = pooled @ fc_w^T + fc_b.  pool_ring [window][N][C],
- * pooled [N][C], logits [N][classes]; fc_w 16-byte aligned when C % 4 == 0. */
+ * pooled [N][C], logits [N][classes]. */
 int csk_co_head_step_f32(const float *h, float *pool_ring, float *pooled, const float *fc_w, const float *fc_b, float *logits,
                          int N, int C, int MV, int64_t P, int window, int head, int count, int emit, int classes, void *stream);
 

@@ -504,3 +504,38 @@ def test_fused_block_step_small_and_ragged_channels(ci, co, res):
         assert ra == rb
         assert torch.equal(sa.y, sb.y) and torch.equal(sa.out, sb.out), cyc
     assert ra is not None and ra[1] == 4
+
+
+@pytest.mark.parametrize("n,c,mv,classes,window", [(5, 256, 50, 60, 7), (3, 256, 36, 400, 4), (2, 70, 50, 11, 3)])
+def test_fused_head_equals_the_three_launches_bitwise(n, c, mv, classes, window):
+    """csk_co_head_step_f32 (spatial pool + pooling-window mean + FC in one launch) against csk_co_spatial_pool_f32 ->
+    csk_co_window_mean_f32 -> csk_fc_f32, the launches it replaces (models/base.py:84-101): identical bits for the ring
+    entry, the pooled features and the logits, on filling (count < window), full and wrapped windows, and on a zero
+    feature (end padding)."""
+    from continual_skeletons_amd import native
+    lib = native.lib()
+    g = torch.Generator().manual_seed(n * 100 + c)
+    P = (n * mv + 3) // 4 * 4
+    w = (torch.rand((classes, c), generator=g) - 0.5).to(DEV)
+    b = (torch.rand((classes,), generator=g) - 0.5).to(DEV)
+    ring_a = torch.zeros((window, n, c), device=DEV)
+    ring_b = torch.zeros((window, n, c), device=DEV)
+    stream = native.stream_of(w)
+    for step in range(2 * window + 3):
+        h = torch.rand((c, P), generator=g).to(DEV) if step != window + 1 else None          # one zero feature on the way
+        head, count = step % window, min(step + 1, window)
+        if h is None:
+            ring_a[head].zero_()
+        else:
+            native.check(lib.csk_co_spatial_pool_f32(native.ptr(h), native.ptr(ring_a[head]), n, c, mv, P, stream), "pool")
+        pooled_a = torch.empty((n, c), device=DEV)
+        native.check(lib.csk_co_window_mean_f32(native.ptr(ring_a), native.ptr(pooled_a), n * c, window, head, count, stream), "mean")
+        logits_a = torch.empty((n, classes), device=DEV)
+        if c % 4 == 0:
+            native.check(lib.csk_fc_f32(native.ptr(pooled_a), native.ptr(w), native.ptr(b), native.ptr(logits_a), n, c, classes, stream), "fc")
+        else:                                   # csk_fc_f32's scalar path has no alignment demands either
+            native.check(lib.csk_fc_f32(native.ptr(pooled_a), native.ptr(w), native.ptr(b), native.ptr(logits_a), n, c, classes, stream), "fc")
+        pooled_b, logits_b = torch.empty((n, c), device=DEV), torch.empty((n, classes), device=DEV)
+        native.check(lib.csk_co_head_step_f32(native.ptr(h), native.ptr(ring_b), native.ptr(pooled_b), native.ptr(w), native.ptr(b),
+                                              native.ptr(logits_b), n, c, mv, P, window, head, count, 1, classes, stream), "head")
+        assert torch.equal(ring_a, ring_b) and torch.equal(pooled_a, pooled_b) and torch.equal(logits_a, logits_b), step
