@@ -374,16 +374,15 @@ def run_latency(pkg, dev, cpu_step, stream_counts=(1, 16), frames=400):
         torch.cuda.synchronize()
         piped = (time.perf_counter() - t0) / frames
         ts.sort()
-        # launches of one 4-frame stride cycle in per-frame stepping: input norm per frame; per block one graph-conv launch
-        # per received frame and one temporal-conv launch (+ the split-K reduction) per emission; the head's three launches
-        # on the predicting frame
+        # launches of one 4-frame stride cycle in per-frame stepping: input norm per frame; per block one graph-conv launch per
+        # received frame and one temporal-conv launch per emission (each + its split-K reduction in latency mode); the head
         launches, recv = 4.0, 4.0
         for i in range(10):
             blk = net.layers[f"layer{i + 1}"]
             emit = recv / blk.stride
-            launches += recv + emit * (2 if blk._state.ksplit > 1 else 1)
+            launches += recv * (2 if blk._state.gcn_ksplit > 1 else 1) + emit * (2 if blk._state.ksplit > 1 else 1)
             recv = emit
-        launches += 3
+        launches += 1                                      # the head: one launch on the predicting frame
         out.append({"streams": streams, "frames_timed": frames, "predictions": preds,
                     "ms_per_frame_p50": round(statistics.median(ts) * 1e3, 4), "ms_per_frame_p99": round(ts[int(0.99 * (frames - 1))] * 1e3, 4),
                     "ms_per_frame_mean": round(sum(ts) / frames * 1e3, 4), "pipelined_ms_per_frame": round(piped * 1e3, 4),
