@@ -178,3 +178,44 @@ def test_clip_forward_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     check_parity(out.cpu(), a["logits"][1:2])
+
+
+@pytest.mark.parametrize("ci,co,v,t,n,ksplit", [(64, 64, 25, 9, 3, 4), (64, 128, 25, 5, 2, 8), (256, 256, 25, 2, 2, 32), (128, 256, 18, 3, 5, 6),
+                                                (40, 70, 25, 4, 2, 3)])
+def test_graph_conv_split_k_entry_vs_oracle_and_unsplit(ci, co, v, t, n, ksplit):
+    """csk_gcn_stage_splitk_f32 (latency mode: the K loop of the graph conv cut into channel ranges over workgroups +
+    gcn_reduce_kernel) on clip-layout operands: within 1e-4 of the oracle and of csk_gcn_stage_f32 (summation order only),
+    identity and conv gcn_residual, ragged channel counts, both skeleton graphs, more ranges asked for than channels allow."""
+    from continual_skeletons_amd import native
+    g = torch.Generator().manual_seed(ci + co + ksplit)
+    m = pkg.GraphConvolution(ci, co, (pkg.ntu_graph() if v == 25 else pkg.kinetics_graph()).A).eval()
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("graph_attn") or ("bn" in name and name.endswith("weight")) or name.endswith("gcn_residual.1.weight"):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand(prm.shape, generator=g) - 0.5)
+            elif name.endswith("weight") and prm.dim() == 4:
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.5 / ci) ** 0.5)
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand(buf.shape, generator=g) - 0.5)
+    sd = {k: x.clone() for k, x in m.state_dict().items()}
+    x = torch.rand(n, ci, t, v, generator=g)
+    with torch.no_grad():
+        want = o.graph_conv(x, sd, "")
+    m = m.to(DEV)
+    xd = x.to(DEV)
+    plain = m(xd)
+    ops = m._packed_ops(xd.device)
+    y = torch.empty_like(plain)
+    part = torch.full((n * ksplit, co, t * v), float("nan"), device=DEV)          # every element the reduction reads must be written
+    rc = native.lib().csk_gcn_stage_splitk_f32(
+        native.ptr(xd), native.ptr(y), native.ptr(ops["w"]), native.ptr(ops["bias"]), native.ptr(ops["ell_src"]),
+        native.ptr(ops["ell_val"]), native.ptr(ops["ell_cnt_host"]), ops["ell_w"], n, ci, co, t, v, ci * t * v, t * v, co * t * v, t * v,
+        ops["res_mode"], ksplit, native.ptr(part), native.stream_of(xd))
+    native.check(rc, "csk_gcn_stage_splitk_f32")
+    check_parity(y.cpu(), want, shape=(ci, co, v, t, n, ksplit))
+    check_parity(y.cpu(), plain.cpu(), note="split-K vs unsplit graph conv (summation order)")

@@ -452,3 +452,35 @@ def test_plan_staleness_check_is_exact_for_every_kind_of_weight_edit():
     assert net._weights_changed() is True
     net.__dict__["_plan_keep"] = (None, net._weight_slots())          # what _refresh_plan_weights does after refolding
     assert net._weights_changed() is False
+
+
+def test_round4_entry_points_validate_their_arguments_without_a_gpu():
+    """csk_gcn_stage_splitk_f32, csk_co_head_step_f32, csk_input_norm_frames_f32: argument errors are reported before
+    anything is launched."""
+    import ctypes as C
+    lib = pkg.native.lib()
+    fake = C.c_void_p(0x1000)
+    cnt = (C.c_int32 * 3)(1, 1, 4)
+
+    def gcn(ksplit=4, partial=fake, ell_cnt=cnt, res=1, c_in=64, c_out=64):
+        return lib.csk_gcn_stage_splitk_f32(fake, fake, fake, fake, fake, fake, ell_cnt, 4, 1, c_in, c_out, 1, 25, 1600, 25, 1600, 25, res,
+                                            ksplit, partial, None)
+    assert gcn(ksplit=0) == -1 and b"ksplit must be in [1, 32]" in lib.csk_last_error()
+    assert gcn(ksplit=33) == -1 and b"ksplit must be in [1, 32]" in lib.csk_last_error()
+    assert gcn(partial=None) == -1 and b"partial-sum buffer" in lib.csk_last_error()
+    assert gcn(res=1, c_out=128) == -1 and b"identity residual" in lib.csk_last_error()
+    dense = (C.c_int32 * 3)(4, 4, 4)                       # more than 1 / 1 / 4 non-zeros per column: not the sparse kernel's graph
+    assert gcn(ell_cnt=dense) == -1 and b"skeleton-sparse" in lib.csk_last_error()
+
+    def head(ring=fake, emit=1, logits=fake, count=1, head_=0, window=4):
+        return lib.csk_co_head_step_f32(fake, ring, fake, fake, fake, logits, 2, 256, 50, 100, window, head_, count, emit, 60, None)
+    assert head(ring=None) == -1 and b"null pointer" in lib.csk_last_error()
+    assert head(head_=4) == -1 and b"bad dims" in lib.csk_last_error()
+    assert head(count=5) == -1 and b"bad dims" in lib.csk_last_error()
+    assert head(logits=None) == -1 and b"emitting step needs" in lib.csk_last_error()
+    assert head(count=0) == -1 and b"emitting step needs" in lib.csk_last_error()
+
+    srcs, dsts = (C.c_void_p * 2)(0x1000, 0x1000), (C.c_void_p * 2)(0x2000, 0)
+    assert lib.csk_input_norm_frames_f32(srcs, dsts, 9, fake, fake, 2, 3, 25, 2, 100, None) == -1 and b"1..8 frames" in lib.csk_last_error()
+    assert lib.csk_input_norm_frames_f32(srcs, dsts, 2, fake, fake, 2, 3, 25, 2, 99, None) == -1 and b"bad dims" in lib.csk_last_error()
+    assert lib.csk_input_norm_frames_f32(srcs, dsts, 2, fake, fake, 2, 3, 25, 2, 100, None) == -1 and b"null frame" in lib.csk_last_error()
