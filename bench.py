@@ -458,6 +458,7 @@ def main():
                     help="stream shards of the CoAGCN leg (its launches are smaller than CoST-GCN's: three interleave better than two, "
                          "measured 982 k -> 1015 k frames/s; four exceed the hardware queues)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the opt-in bf16x3 precision-mode leg")
+    ap.add_argument("--no-config5-leg", action="store_true", help="N = 1 only: skip the configs[4] per-GPU shard leg (1024 clips in one forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the 1- and 16-stream per-frame latency leg of the online workload")
     ap.add_argument("--latency-frames", type=int, default=400, help="frames timed per stream count by the latency leg")
@@ -629,17 +630,18 @@ def main():
                               "note": "6 bf16 MFMA products per fp32 product: executed FLOPs = 6 x the fp32-equivalent; peak 2.5 PFLOP/s dense bf16"},
                 "fp32_path_tcn_stage_avg_launch_ms": round(avg_launch_s * 1e3, 4),
                 "scope": "clip kernels only (csk_tcn_stage_bf16x3, csk_gcn_stage_bf16x3); the continual step kernels stay exact fp32 (DESIGN.md)"}
-        if use_dist:
+        if use_dist or not args.no_config5_leg:
             # BASELINE.json configs[4]: batch 8192 over 8 GPUs = 1024 clips per GPU + the RCCL logit all-gather.  Reported
             # beside the 256 / GPU weak-scaling headline (which stays comparable with the N = 1 line); at N = 8 this IS
-            # configs[4], at other N the same per-GPU shard.
+            # configs[4], at other N the same per-GPU shard (N = 1: one rank's shard, no collective).
             b5 = args.config5_batch
             steps5 = max(2, args.steps // 4)
             dt5, _, _ = clip_leg(b5, steps5, 1, seed0=300)
             f5a, f5e, f5y = workmodel.clip_totals(b5 * NTU["M"])
             line["config5"] = {
-                "workload": f"ST-GCN clip inference, {b5} clips/GPU x {world} GPUs = global batch {b5 * world}, logit all-gather "
-                            f"over {backend} [configs[4]{'' if (b5 == 1024 and world == 8) else ' per-GPU shard shape'}]",
+                "workload": f"ST-GCN clip inference, {b5} clips/GPU x {world} GPUs = global batch {b5 * world}, " +
+                            (f"logit all-gather over {backend}" if use_dist else "one rank's shard, no collective") +
+                            f" [configs[4]{'' if (b5 == 1024 and world == 8) else ' per-GPU shard shape'}]",
                 "value": round(b5 * world * steps5 / dt5, 2), "unit": "clips/s", "clips_per_gpu": b5, "global_batch": b5 * world,
                 "steps": steps5, "ms_per_step": round(dt5 / steps5 * 1e3, 3),
                 "roofline_config": workmodel.roofline_config(f5a * world, f5y * world, dt5 / steps5, f5e * world)}

@@ -48,7 +48,7 @@ def make():
     else:
         net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
         bench.randomise_(net, seed=0)
-    if args.force_ksplit > 1:
+    if args.force_ksplit >= 1:
         for blk in net.layers.values():
             if blk.out_channels >= args.ksplit_min_c:
                 blk._pick_ksplit = lambda p, k=args.force_ksplit: k      # measurement only: overrides the block's policy
