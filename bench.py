@@ -685,7 +685,7 @@ def main():
                                   "timing": "single stream shard, launches driven from Python with HIP events around every "
                                             "tcn_step_kernel launch (blocks 5-10; blocks 1-4 use the fused block kernel) of 4 cycles of "
                                             "4 frames: the launch shape of tools/online_pass.py --shards 1, whose rocprofv3 per-layer "
-                                            "table is profiles/r03_online_1shard.md (rows L5-L10 tcn_step)",
+                                            "table is profiles/r04_online_1shard.md (rows L5-L10 tcn_step)",
                                   "traffic": straffic["hbm_bytes_per_launch"] if straffic and straffic.get("streams") == args.streams else None,
                                   "traffic_source": (f"{straffic.get('source')} (committed PMC passes, not collected by this run)")
                                   if straffic and straffic.get("streams") == args.streams else None},
