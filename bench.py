@@ -397,14 +397,24 @@ def run_latency(pkg, dev, cpu_step, stream_counts=(1, 16), frames=400):
             "note": "frames 1-3 of a stride cycle run fewer blocks than the 4th (strides 2, 2): p99 is the predicting frame"}
 
 
-def load_traffic(name="traffic_tcn_stage.json"):
-    """Per-launch HBM bytes of the dominant kernel from the COMMITTED PMC summary (profiles/; separate rocprofv3 --pmc
-    passes of tools/profile.sh -- not measured by this run, the line says so under `traffic_source`), or None."""
+def load_traffic(name="traffic_tcn_stage.json", batch=None, streams=None):
+    """Per-launch HBM bytes of the dominant kernel from the COMMITTED PMC summaries (profiles/; separate rocprofv3 --pmc
+    passes of tools/profile_r05.sh condensed by tools/summarize_pmc.py -- not measured by this run, the line says so under
+    `traffic_source`).  The clip file holds one entry per profiled batch size (`by_batch`); returns the entry that matches
+    `batch` / `streams`, or None when no pass was committed for that size."""
     p = os.path.join(ROOT, "profiles", name)
-    if os.path.exists(p):
-        with open(p) as f:
-            return json.load(f)
-    return None
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        d = json.load(f)
+    if batch is not None:
+        for e in d.get("by_batch", [d]):
+            if e.get("batch") == batch:
+                return e
+        return None
+    if streams is not None and d.get("streams") != streams:
+        return None
+    return d
 
 
 def self_launch(n):
@@ -413,27 +423,48 @@ def self_launch(n):
     GPU, rendezvous on 127.0.0.1), relays rank 0's single JSON line on stdout (anything else the ranks print goes to
     stderr) and returns the launcher's exit code.  The parent makes NO GPU call -- no torch.cuda.*, no _bootstrap.load(), no
     process group -- before or after starting its children, and it never re-executes itself: it only spawns and exits."""
-    import socket
+    import signal
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    # --standalone: the launcher binds its own rendezvous port (no bind-close-rebind race with other processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
+    # own session: the launcher and its N ranks form one process group that can be signalled as a whole, so that a driver
+    # timeout that terminates this parent does not leave rank processes holding the GPUs
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+
+    def forward(signum, _frame):
+        try:
+            os.killpg(proc.pid, signum)
+        except ProcessLookupError:
+            pass
+    old_handlers = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
     lines = 0
-    for ln in proc.stdout:
-        if ln.startswith("{") and lines == 0:
-            sys.stdout.write(ln)
-            sys.stdout.flush()
-            lines += 1
-        else:
+    try:
+        for ln in proc.stdout:
+            if ln.startswith("{"):
+                lines += 1
+                if lines == 1:
+                    sys.stdout.write(ln)
+                    sys.stdout.flush()
+                    continue
             sys.stderr.write(ln)
-    rc = proc.wait()
+        rc = proc.wait()
+    finally:
+        if proc.poll() is None:                                # we are being torn down: take the ranks with us
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                proc.wait(timeout=10)
+            except (ProcessLookupError, subprocess.TimeoutExpired):
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     if rc == 0 and lines != 1:
-        sys.stderr.write(f"bench.py: the {n} ranks exited 0 but printed {lines} JSON lines\n")
+        sys.stderr.write(f"bench.py: the {n} ranks exited 0 but printed {lines} JSON lines (exactly one expected)\n")
         rc = 1
     return rc
 
@@ -447,7 +478,10 @@ def main():
                     help="'both' (default): primary metric = clip, CoST-GCN online step reported in the same line")
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--streams", type=int, default=1024, help="concurrent CoST-GCN streams per GPU")
-    ap.add_argument("--step-cycles", type=int, default=16, help="timed 4-frame cycles of the online workload")
+    ap.add_argument("--step-cycles", type=int, default=100,
+                    help="timed launch cycles of the online workload (default 100 cycles of 4 frames = 400 timed frames per stream, SURVEY 8d)")
+    ap.add_argument("--kernel-cycles", type=int, default=17,
+                    help="cycles of the single-shard pass that times every tcn_step_kernel launch with HIP events (6 launches per cycle: 17 -> 102)")
     ap.add_argument("--stream-shards", type=int, default=2, help="independent stream shards on separate HIP streams")
     ap.add_argument("--frames-per-launch", type=int, default=4, help="frames advanced per launch cycle of the online workload")
     ap.add_argument("--config5-batch", type=int, default=1024,
@@ -478,6 +512,8 @@ def main():
     # N > 1 code path of this script on a 1-GPU box; real runs use the default, "nccl" = RCCL, one rank per GPU
     backend = os.environ.get("CSK_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    if os.environ.get("CSK_BENCH_SAME_DEVICE") == "1":     # test hook: every rank on device 0 (what a launcher that drops LOCAL_RANK does)
+        dev_index = 0
     # CSK_BENCH_FORCE_DIST=1: initialise the process group and run every collective of the N > 1 path with ONE rank as
     # well (what a 1-GPU box can exercise of RCCL: tests/test_gpu_multirank.py)
     use_dist = world > 1 or (os.environ.get("CSK_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
@@ -510,21 +546,34 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def ranks_seen():
-        """Distinct (hostname, device) pairs among the ranks: == world when every rank has a GPU of its own."""
-        if not use_dist:
-            return 1
-        import hashlib
+    def device_ident():
         import socket
         try:
-            ident = f"{socket.gethostname()}/{torch.cuda.get_device_properties(dev).uuid}"
+            return f"{socket.gethostname()}/{torch.cuda.get_device_properties(dev).uuid}"
         except Exception:
-            ident = f"{socket.gethostname()}/{dev_index}"
-        h = int.from_bytes(hashlib.sha1(ident.encode()).digest()[:7], "little")
-        mine = torch.tensor([h], device=dev, dtype=torch.int64)
-        allh = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allh, mine)
-        return len({int(t.item()) for t in allh})
+            return f"{socket.gethostname()}/cuda:{dev_index}"
+
+    def per_rank_table(local_ms_per_step):
+        """[{rank, device_uuid, ms_per_step}] over all ranks (fixed-size byte tensors through all_gather: works with RCCL and
+        gloo alike); `ranks_seen` = distinct devices among them, == world when every rank has a GPU of its own."""
+        ident = device_ident().encode()[:96]
+        if not use_dist:
+            return [{"rank": 0, "device_uuid": ident.decode(), "ms_per_step": round(local_ms_per_step, 3)}]
+        buf = torch.zeros(104, dtype=torch.uint8, device=dev)
+        buf[:len(ident)] = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+        ms = torch.tensor([local_ms_per_step], dtype=torch.float64, device=dev).view(torch.uint8)
+        buf[96:104] = ms
+        allb = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(allb, buf)
+        rows = []
+        for r, b in enumerate(allb):
+            b = b.cpu()
+            name = bytes(b[:96].tolist()).rstrip(b"\0").decode(errors="replace")
+            rows.append({"rank": r, "device_uuid": name, "ms_per_step": round(float(b[96:104].clone().view(torch.float64).item()), 3)})
+        return rows
+
+    def ranks_seen(rows):
+        return len({r["device_uuid"] for r in rows})
 
     line = None
     B = args.batch
@@ -564,6 +613,8 @@ def main():
             tcn_ms = lt.total_ms()
             n_launch = len(lt.records)
         assert out.shape == (batch * world, NTU["classes"]) and bool(torch.isfinite(out).all())
+        if info is not None:
+            info["local_ms_per_step"] = dt / steps * 1e3           # this rank's own clock (per_rank table)
         dt = max_over_ranks(dt)
         if info is not None and precision != "f32":
             got = net(x)
@@ -577,13 +628,16 @@ def main():
         torch.cuda.empty_cache()
         return dt, tcn_ms, n_launch
 
+    per_rank = None
     if do_clip:
-        dt, tcn_ms, n_launch = clip_leg(B, args.steps, args.warmup)
+        inf1 = {}
+        dt, tcn_ms, n_launch = clip_leg(B, args.steps, args.warmup, info=inf1)
+        per_rank = per_rank_table(inf1["local_ms_per_step"])
         clips = B * world * args.steps
         flops_launch = tcn_flops_per_clip_forward(B * NTU["M"]) / 10.0       # average over the 10 launches / step
         avg_launch_s = tcn_ms / 1e3 / max(1, n_launch)
         achieved = flops_launch / avg_launch_s / 1e12
-        traffic = load_traffic()
+        traffic = load_traffic(batch=B)
         cfa, cfe, cby = workmodel.clip_totals(B * NTU["M"])     # per rank and step: FLOPs (SURVEY accounting), executed, bytes
         line = {
             "metric": "clips/sec (ST-GCN clip forward, NTU-60 shape; CoST-GCN online step reported under costgcn_online)",
@@ -600,15 +654,15 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches_timed": n_launch,
                          "flops_per_launch": flops_launch,
-                         "traffic": traffic["hbm_bytes_per_launch"] if traffic and B == traffic.get("batch") else None,
-                         "traffic_source": (f"{traffic.get('source')} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                            "not collected by this run)") if traffic and B == traffic.get("batch") else None},
+                         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                         "traffic_source": (f"{traffic.get('source')} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at this batch, "
+                                            "not collected by this run)") if traffic else "no committed PMC pass at this batch size"},
             # whole-config roofline (SURVEY 8d / BASELINE.md 3): algorithmic FLOPs and fused-block minimum bytes of one
             # step (all ranks) against the time of one step; dense aggregation credited under flops_alg, only the
             # non-zeros the sparse kernel executes under flops_executed
-            "roofline_config": workmodel.roofline_config(cfa * world, cby * world, dt / args.steps, cfe * world),
+            "roofline_config": workmodel.roofline_config(cfa * world, cby * world, dt / args.steps, cfe * world, n_gpus=world),
             "cpu_baseline": cpu,
-            "ranks_seen": ranks_seen(), "collective_backend": backend if use_dist else None,
+            "ranks_seen": ranks_seen(per_rank), "per_rank": per_rank, "collective_backend": backend if use_dist else None,
         }
         if not args.no_split_leg:
             # OPT-IN precision mode "bf16x3" (csrc/tcn_split.hip): the same workload with the temporal conv on the bf16 matrix
@@ -636,24 +690,35 @@ def main():
             # configs[4], at other N the same per-GPU shard (N = 1: one rank's shard, no collective).
             b5 = args.config5_batch
             steps5 = max(2, args.steps // 4)
-            dt5, _, _ = clip_leg(b5, steps5, 1, seed0=300)
+            dt5, tcn5_ms, n5 = clip_leg(b5, steps5, 1, seed0=300)
             f5a, f5e, f5y = workmodel.clip_totals(b5 * NTU["M"])
+            fl5 = tcn_flops_per_clip_forward(b5 * NTU["M"]) / 10.0
+            ach5 = fl5 / (tcn5_ms / 1e3 / max(1, n5)) / 1e12
+            traffic5 = load_traffic(batch=b5)
             line["config5"] = {
                 "workload": f"ST-GCN clip inference, {b5} clips/GPU x {world} GPUs = global batch {b5 * world}, " +
                             (f"logit all-gather over {backend}" if use_dist else "one rank's shard, no collective") +
                             f" [configs[4]{'' if (b5 == 1024 and world == 8) else ' per-GPU shard shape'}]",
                 "value": round(b5 * world * steps5 / dt5, 2), "unit": "clips/s", "clips_per_gpu": b5, "global_batch": b5 * world,
                 "steps": steps5, "ms_per_step": round(dt5 / steps5 * 1e3, 3),
-                "roofline_config": workmodel.roofline_config(f5a * world, f5y * world, dt5 / steps5, f5e * world)}
+                # the dominant kernel of this leg, timed live on rank 0 exactly as the headline's (HIP events around every launch)
+                "roofline": {"bound": "mfma", "kernel": "tcn_stage_kernel", "achieved": round(ach5, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(ach5 / PEAK_F32_MFMA_TFLOPS, 4),
+                             "avg_launch_ms": round(tcn5_ms / max(1, n5), 4), "launches_timed": n5, "flops_per_launch": fl5,
+                             "traffic": traffic5["hbm_bytes_per_launch"] if traffic5 else None,
+                             "traffic_source": (f"{traffic5.get('source')} (committed rocprofv3 --pmc passes at this batch, not collected by this run)")
+                             if traffic5 else "no committed PMC pass at this batch size"},
+                "roofline_config": workmodel.roofline_config(f5a * world, f5y * world, dt5 / steps5, f5e * world, n_gpus=world)}
 
     if do_step:
         sdt, stcn_ms, sn, sbytes = run_step_workload(pkg, dev, args.streams, args.step_cycles, 2, rank, world, parallel, dist, args.stream_shards, fpl=args.frames_per_launch, use_dist=use_dist)
+        sdt_local = sdt
         sdt = max_over_ranks(sdt)
         # kernel-level timing: launches must not overlap and must go through the Python hook -> short single-shard pass
         gc.collect()                 # engines hold reference cycles (state-dict hooks); free their slabs now
         torch.cuda.empty_cache()
-        _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, 4, 1, rank, world, parallel, dist, 1, native_plan=False, use_dist=use_dist)
-        kcycles = 4
+        kcycles = max(1, args.kernel_cycles)
+        _, stcn_ms, sn, _ = run_step_workload(pkg, dev, args.streams, kcycles, 1, rank, world, parallel, dist, 1, native_plan=False, use_dist=use_dist)
         # the timed launches are the tcn_step_kernel launches of a cycle: blocks 5-10 (blocks 1-4, C_out = 64, advance with
         # the fused csk_co_block_step_f32 launch, which does not go through the hook)
         step_layers = [l for l in workmodel.step_layers(4) if l["co"] > 64]
@@ -661,7 +726,7 @@ def main():
         assert sn == kcycles * len(step_layers), (sn, len(step_layers))
         fps = args.frames_per_launch * args.streams * world * args.step_cycles / sdt
         ach = tfl * kcycles / (stcn_ms / 1e3) / 1e12 if stcn_ms > 0 else 0.0
-        straffic = load_traffic("traffic_tcn_step.json")
+        straffic = load_traffic("traffic_tcn_step.json", streams=args.streams)
         sfa, sfe, sby = workmodel.step_totals(args.streams * NTU["M"], args.frames_per_launch)   # per rank and cycle
         thr = None
         if args.frames_per_launch != 8:      # throughput mode: two stride cycles per launch (adds 4 frames of latency)
@@ -673,7 +738,7 @@ def main():
             tfa, tfe, tby = workmodel.step_totals(args.streams * NTU["M"], 8)
             thr = {"frames_per_launch": 8, "value": round(8 * args.streams * world * args.step_cycles / tdt, 1),
                    "unit": "frames/s",
-                   "roofline_config_frac": workmodel.roofline_config(tfa * world, tby * world, tdt / args.step_cycles, tfe * world)["frac"]}
+                   "roofline_config_frac": workmodel.roofline_config(tfa * world, tby * world, tdt / args.step_cycles, tfe * world, n_gpus=world)["frac"]}
         step_info = {"metric": "skeleton frames/sec (CoST-GCN online step, NTU-60 shape)", "value": round(fps, 1),
                      "unit": "frames/s", "streams_per_gpu": args.streams, "stream_shards": args.stream_shards, "frames_per_launch": args.frames_per_launch, "ms_per_frame_step": round(sdt / args.step_cycles / args.frames_per_launch * 1e3, 4),
                      "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes[0] / 1e9, 3),
@@ -683,13 +748,13 @@ def main():
                                   "avg_launch_ms": round(stcn_ms / max(1, sn), 4),
                                   "flops_per_launch": tfl / len(step_layers),
                                   "timing": "single stream shard, launches driven from Python with HIP events around every "
-                                            "tcn_step_kernel launch (blocks 5-10; blocks 1-4 use the fused block kernel) of 4 cycles of "
+                                            f"tcn_step_kernel launch (blocks 5-10; blocks 1-4 use the fused block kernel) of {kcycles} cycles of "
                                             "4 frames: the launch shape of tools/online_pass.py --shards 1, whose rocprofv3 per-layer "
-                                            "table is profiles/r04_online_1shard.md (rows L5-L10 tcn_step)",
-                                  "traffic": straffic["hbm_bytes_per_launch"] if straffic and straffic.get("streams") == args.streams else None,
+                                            "table is profiles/r05_online_1shard.md (rows L5-L10 tcn_step)",
+                                  "traffic": straffic["hbm_bytes_per_launch"] if straffic else None,
                                   "traffic_source": (f"{straffic.get('source')} (committed PMC passes, not collected by this run)")
-                                  if straffic and straffic.get("streams") == args.streams else None},
-                     "roofline_config": workmodel.roofline_config(sfa * world, sby * world, sdt / args.step_cycles, sfe * world),
+                                  if straffic else "no committed PMC pass at this stream count"},
+                     "roofline_config": workmodel.roofline_config(sfa * world, sby * world, sdt / args.step_cycles, sfe * world, n_gpus=world),
                      "throughput_mode": thr, "cpu_baseline": cpu_step, "config": "BASELINE.json configs[2]"}
         if world == 1 and not args.no_latency_leg:
             gc.collect()
@@ -711,12 +776,22 @@ def main():
         line["agcn_kinetics"] = run_config4(pkg, dev, parallel, batch=args.config4_batch, streams=args.config4_streams,
                                             shards=min(args.config4_shards, max(1, args.config4_streams)), cpu_threads=0 if args.no_cpu_baseline else host_cpu_threads(),
                                             cpu_budget=args.cpu_budget_config4)
-    line.setdefault("ranks_seen", ranks_seen())
+    if per_rank is None:                                 # --workload step: the table carries the online leg's clock
+        per_rank = per_rank_table(sdt_local / args.step_cycles * 1e3)
+    line.setdefault("per_rank", per_rank)
+    line.setdefault("ranks_seen", ranks_seen(per_rank))
     line.setdefault("collective_backend", backend if use_dist else None)
+    # one rank per GPU is the contract of an RCCL run: ranks that share a device (a launcher that did not pin LOCAL_RANK)
+    # would print a throughput that is not N GPUs' -- the line is still printed, marked invalid, and the exit code says so
+    bad = use_dist and backend == "nccl" and line["ranks_seen"] != world
+    if bad:
+        line["error"] = f"ranks_seen {line['ranks_seen']} != n_gpus {world}: ranks share a device; this line is INVALID"
     if rank == 0:
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
+    if bad:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

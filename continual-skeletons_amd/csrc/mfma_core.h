@@ -121,36 +121,91 @@ struct WStage {
     }
 };
 
+// WStage for a full 9-tap chunk of a 128-row tile: 9 * KC * 32 = 2304 f32x4 = exactly 9 per thread, and slot u of a thread
+// is tap u, channel row tid / 32, rows 4 * (tid % 32) ..: the global and LDS offsets of the 9 slots differ by wave-uniform
+// constants (Cpad * Mpad elements / KC * 128 floats), so ONE offset register each replaces the 18 of the general form.
+struct WStage9x128 {
+    unsigned goff0, loff0, gstride;
+    f32x4 v[9];
+    __device__ __forceinline__ void setup(int Cpad, int Mpad, int tid) {
+        goff0 = (unsigned)((tid >> 5) * Mpad + (tid & 31) * 4);
+        loff0 = (unsigned)(tid * 4);
+        gstride = (unsigned)(Cpad * Mpad);
+    }
+    __device__ __forceinline__ void issue_slot(int u, const float *__restrict__ chunk_base) {
+        v[u] = *reinterpret_cast<const f32x4 *>(chunk_base + (size_t)u * gstride + goff0);
+    }
+    __device__ __forceinline__ void issue(const float *__restrict__ chunk_base) {
+#pragma unroll
+        for (int u = 0; u < 9; ++u) issue_slot(u, chunk_base);
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Wl) const {
+#pragma unroll
+        for (int u = 0; u < 9; ++u) *reinterpret_cast<f32x4 *>(Wl + u * (KC * 128) + loff0) = v[u];
+    }
+};
+
+// The same for a 64-row tile: 9 * KC * 16 = 1152 f32x4 = 4.5 per thread; slot u of a thread is tap 2 u + tid / 128, channel
+// row (tid / 16) % 8; the upper half of the threads has no slot 4 and repeats its slot 3 (same value to the same address).
+struct WStage9x64 {
+    unsigned goff0, loff0, gstride, u4;
+    f32x4 v[5];
+    __device__ __forceinline__ void setup(int Cpad, int Mpad, int tid) {
+        goff0 = (unsigned)(((tid >> 7) * Cpad + ((tid >> 4) & 7)) * Mpad + (tid & 15) * 4);
+        loff0 = (unsigned)(tid * 4);
+        gstride = (unsigned)(2 * Cpad * Mpad);
+        u4 = tid >= 128 ? 3u : 4u;
+    }
+    __device__ __forceinline__ void issue_slot(int u, const float *__restrict__ chunk_base) {
+        if (u < 4) v[u] = *reinterpret_cast<const f32x4 *>(chunk_base + (size_t)u * gstride + goff0);
+        else if (u == 4) v[4] = *reinterpret_cast<const f32x4 *>(chunk_base + u4 * gstride + goff0);
+    }
+    __device__ __forceinline__ void issue(const float *__restrict__ chunk_base) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) issue_slot(u, chunk_base);
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Wl) const {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4 *>(Wl + u * 1024 + loff0) = v[u];
+        *reinterpret_cast<f32x4 *>(Wl + u4 * 1024 + loff0) = v[4];
+    }
+};
+
 // activations: KC channel rows x span positions of one segment -> Bl [KC][ldb]; positions outside [0, TV)
 // and channels >= C read as zero (conv zero padding / channel padding): the address is clamped into the
 // tensor and the value replaced by 0 with a select, so the load itself is unconditional.
 template <int NJ>
 struct BStage {
     static constexpr int RPW = KC / (NTHREADS / 64);   // rows per wave
-    unsigned goff[NJ];   // clamped position inside a channel row
-    unsigned loff[NJ];   // position inside an LDS row
+    // slot u of a lane is position j = min(u * 64 + lane, span - 1) of the LDS row = position clamp(pbase + j) of the channel
+    // row; both are recomputed where they are used (two or three integer operations per access, boundary tiles only) instead
+    // of 2 NJ registers held across the K loop -- the 9-tap kernels run at the 256-register limit
+    int lane_, spanm1, pbase_, tvm1;
     unsigned valid;      // bit u: position is inside [0, TV)
     float v[RPW][NJ];
     __device__ __forceinline__ void setup(int pbase, int span, int TV, int lane) {
         valid = 0;
+        lane_ = lane;
+        spanm1 = span - 1;
+        pbase_ = pbase;
+        tvm1 = TV - 1;
 #pragma unroll
         for (int u = 0; u < NJ; ++u) {
-            const int j = min(u * 64 + lane, span - 1);
-            const int pp = pbase + j;
-            goff[u] = (unsigned)min(max(pp, 0), TV - 1);
-            loff[u] = (unsigned)j;
+            const int pp = pbase + min(u * 64 + lane, span - 1);
             valid |= (pp >= 0 && pp < TV) ? (1u << u) : 0u;
         }
     }
+    __device__ __forceinline__ unsigned goff(int u) const { return (unsigned)min(max(pbase_ + min(u * 64 + lane_, spanm1), 0), tvm1); }
     // slot u of every row this wave owns (used to trickle the loads between MFMA groups)
     __device__ __forceinline__ void issue_slot(int u, const float *__restrict__ seg_base, int C, int64_t chan_stride,
                                                int c0, int wave) {
         if (u >= NJ) return;
+        const unsigned g = goff(u);
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int c = c0 + wave + rr * (NTHREADS / 64);
             const float *src = seg_base + (int64_t)min(c, C - 1) * chan_stride;
-            const float x = src[goff[u]];
+            const float x = src[g];
             v[rr][u] = ((c < C ? valid : 0u) >> u) & 1u ? x : 0.f;
         }
     }
@@ -158,16 +213,7 @@ struct BStage {
     __device__ __forceinline__ void issue(const float *__restrict__ seg_base, int C, int64_t chan_stride, int c0,
                                           int wave) {
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int c = c0 + wave + rr * (NTHREADS / 64);
-            const float *src = seg_base + (int64_t)min(c, C - 1) * chan_stride;
-            const unsigned m = c < C ? valid : 0u;
-#pragma unroll
-            for (int u = 0; u < NJ; ++u) {
-                const float x = src[goff[u]];
-                v[rr][u] = ((m >> u) & 1u) ? x : 0.f;
-            }
-        }
+        for (int u = 0; u < NJ; ++u) issue_slot(u, seg_base, C, chan_stride, c0, wave);
     }
     // third G of the next chunk's loads: sweeps 3G .. 3G+2 (plus 3G+9 .. for long spans)
     template <int G>
@@ -184,7 +230,7 @@ struct BStage {
         for (int rr = 0; rr < RPW; ++rr) {
             float *dst = Bl + (wave + rr * (NTHREADS / 64)) * ldb;
 #pragma unroll
-            for (int u = 0; u < NJ; ++u) dst[loff[u]] = v[rr][u];
+            for (int u = 0; u < NJ; ++u) dst[min(u * 64 + lane_, spanm1)] = v[rr][u];
         }
     }
 };
@@ -262,6 +308,66 @@ __device__ __forceinline__ void mfma_taps(const float *__restrict__ Wl, const fl
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+    }
+}
+
+// Compile-time form of mfma_taps for NTAPS consecutive taps starting at r0: straight-line code, so the compiler can issue
+// the LDS fragment reads of tap r + 1 under the MFMAs of tap r.  The rolled loop above exposes the LDS latency once per
+// tap, which a wave only hides while its SIMD partner (the other workgroup's wave) is issuing MFMAs too -- not while the
+// partner sits in its barrier / commit phase and this wave has the matrix pipe to itself.
+template <int MT, int NTAPS>
+__device__ __forceinline__ void mfma_taps_ct(const float *__restrict__ Wl, const float *__restrict__ Bl, int r0, int ldb, int tapB,
+                                             int offA, int off0, int off1, int kh, f32x16 (&acc)[2][2]) {
+    const float *wr = Wl + r0 * (KC * MT) + offA + kh * MT;
+    const float *br = Bl + r0 * tapB + kh * ldb;
+#pragma unroll
+    for (int r = 0; r < NTAPS; ++r) {
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const float a0 = wr[r * (KC * MT) + 2 * s * MT], a1 = wr[r * (KC * MT) + 2 * s * MT + 32];
+            const float b0 = br[r * tapB + 2 * s * ldb + off0], b1 = br[r * tapB + 2 * s * ldb + off1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
+// The same with the lookahead bounded by hand: the fragment reads of tap r + 1 are issued in front of the 16 MFMAs of tap r
+// (operands double-buffered in registers, one scheduling fence per tap).  For callers whose LDS strides are compile-time
+// constants (the step kernels): there every read of mfma_taps_ct has an immediate offset, the compiler hoists all 48 of a
+// segment to its top and the kernel spills.
+template <int MT, int NTAPS>
+__device__ __forceinline__ void mfma_taps_pipe(const float *__restrict__ Wl, const float *__restrict__ Bl, int r0, int ldb, int tapB,
+                                               int offA, int off0, int off1, int kh, f32x16 (&acc)[2][2]) {
+    const float *wr = Wl + r0 * (KC * MT) + offA + kh * MT;
+    const float *br = Bl + r0 * tapB + kh * ldb;
+    float a[2][KC / 2][2], b[2][KC / 2][2];
+#pragma unroll
+    for (int s = 0; s < KC / 2; ++s) {
+        a[0][s][0] = wr[2 * s * MT]; a[0][s][1] = wr[2 * s * MT + 32];
+        b[0][s][0] = br[2 * s * ldb + off0]; b[0][s][1] = br[2 * s * ldb + off1];
+    }
+#pragma unroll
+    for (int r = 0; r < NTAPS; ++r) {
+        if (r + 1 < NTAPS) {
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) {
+                a[(r + 1) & 1][s][0] = wr[(r + 1) * (KC * MT) + 2 * s * MT];
+                a[(r + 1) & 1][s][1] = wr[(r + 1) * (KC * MT) + 2 * s * MT + 32];
+                b[(r + 1) & 1][s][0] = br[(r + 1) * tapB + 2 * s * ldb + off0];
+                b[(r + 1) & 1][s][1] = br[(r + 1) * tapB + 2 * s * ldb + off1];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][0], b[r & 1][s][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][0], b[r & 1][s][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][1], b[r & 1][s][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][1], b[r & 1][s][1], acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -96,7 +96,7 @@ struct StepParams {
 // E = emissions per workgroup tile (folded into the tile's column axis, see RingStage), HS = head_step of the launch
 // (1, or 2 for a stride-2 block; only meaningful for E > 1).  SPLIT = false is the throughput kernel; the split-K form
 // is a separate instantiation (E = 1) so that its extra index arithmetic costs the default path nothing.
-template <int MT, int E, int HS, bool SPLIT>
+template <int MT, int E, int HS, bool SPLIT, bool K9 = true>
 __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx, const int by, const int bz, float *smem) {
     constexpr int NT = 16384 / MT;
     constexpr int NP = NT / E;                      // positions per tile
@@ -154,6 +154,7 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
         rs.window(first, 1, p.slots, nwin, p.C, P);
         rs.issue(rbase, Cl, P, 0);
         const int t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
+        constexpr bool k9 = K9;                          // 9 taps: straight-line 3-tap MFMA segments, reads one tap ahead (mfma_taps_pipe)
         int c0 = 0;
         for (; c0 + KC < CpadL; c0 += KC) {
             __syncthreads();
@@ -166,19 +167,22 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
             for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<0>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            mfma_taps<MT>(Wl, Bl, 0, t1, NP, KC * NP, offA, off0, off1, kh, acc);
+            if (k9) mfma_taps_pipe<MT, 3>(Wl, Bl, 0, NP, KC * NP, offA, off0, off1, kh, acc);
+            else mfma_taps<MT>(Wl, Bl, 0, t1, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<1>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NP, KC * NP, offA, off0, off1, kh, acc);
+            if (k9) mfma_taps_pipe<MT, 3>(Wl, Bl, 3, NP, KC * NP, offA, off0, off1, kh, acc);
+            else if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<2>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NP, KC * NP, offA, off0, off1, kh, acc);
+            if (k9) mfma_taps_pipe<MT, 3>(Wl, Bl, 6, NP, KC * NP, offA, off0, off1, kh, acc);
+            else if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
@@ -292,7 +296,7 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
     }
 }
 
-template <int MT, int E, int HS, bool SPLIT>
+template <int MT, int E, int HS, bool SPLIT, bool K9>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware work-item order (mfma_core.h): every XCD walks a contiguous range of items; m-tile fastest, then emission
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams 
     // same positions all but a few slots of it); with a plain (x, y, z) grid they sat gridDim.x dispatches apart, by when
     // the window had left the 4 MB L2 (C = 256 launches fetched 966 MB for 525 MB of operands)
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    tcn_step_tile<MT, E, HS, SPLIT>(p, (int)(wid / (p.gy * p.gz)), (int)(wid % p.gy), (int)((wid / p.gy) % p.gz), smem);
+    tcn_step_tile<MT, E, HS, SPLIT, K9>(p, (int)(wid / (p.gy * p.gz)), (int)(wid % p.gy), (int)((wid / p.gy) % p.gz), smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -633,7 +637,8 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     const int NP = NT / E;
     void (*kern)(StepParams);
     size_t stage_floats;
-#define CSK_PICK(MT_, E_, HS_, SP_) (kern = tcn_step_kernel<MT_, E_, HS_, SP_>, stage_floats = RingStage<16384 / MT_ / E_, 8 + (E_ - 1) * HS_ + 1>::LDS_FLOATS)
+    const bool k9 = k == 9 && !csk_diag_flag("CSK_STEP_NOCT");     // E > 1 implies k == 9 (folding condition above)
+#define CSK_PICK(MT_, E_, HS_, SP_) (kern = (E_ > 1 || k9) ? tcn_step_kernel<MT_, E_, HS_, SP_, true> : tcn_step_kernel<MT_, E_, HS_, SP_, (E_ > 1)>, stage_floats = RingStage<16384 / MT_ / E_, 8 + (E_ - 1) * HS_ + 1>::LDS_FLOATS)
     if (p.ksplit > 1) {
         if (big) E == 2 ? (head_step == 2 ? CSK_PICK(128, 2, 2, true) : CSK_PICK(128, 2, 1, true)) : CSK_PICK(128, 1, 1, true);
         else CSK_PICK(64, 1, 1, true);

@@ -15,6 +15,8 @@
 // Tiling: 256 threads = 4 waves, each wave owns a 64x64 output tile (2x2 MFMA 32x32 accumulators);
 // workgroup tile MT x NT with MT*NT = 16384 (64x256 for C_out = 64, 128x128 otherwise).  K loop walks
 // channel chunks of KC = 8; one activation chunk in LDS serves all 9 taps.
+#include <type_traits>
+
 #include "mfma_core.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -33,7 +35,7 @@ struct TcnParams {
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
 
-template <int MT, int NJ>
+template <int MT, int NJ, bool K9 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams p) {
     constexpr int OCC = 2;   // 3 (epilogue operands loaded after the K loop, <= 168 registers) was measured: the K loop's
                              // staging registers then spill and the stage runs 13-19 % slower
@@ -131,9 +133,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V;
         const int64_t cs = (int64_t)p.Tin * V;
         const float *wbase = p.w + m0;
-        ws.setup(p.K, p.Cpad, p.Mpad, tid);
+        // 9-tap chunks: the compact weight staging (offsets of a thread's slots differ by wave-uniform constants)
+        using WS9 = typename std::conditional<MT == 128, WStage9x128, WStage9x64>::type;
+        typename std::conditional<K9, WS9, WStage<MT> &>::type ws1 = [&]() -> decltype(auto) {
+            if constexpr (K9) { WS9 w9; w9.setup(p.Cpad, p.Mpad, tid); return w9; }
+            else { ws.setup(p.K, p.Cpad, p.Mpad, tid); return (ws); }
+        }();
         auto phase1 = [&](auto &bx) {
-            ws.issue(wbase);
+            // straight-line 3-tap MFMA segments (mfma_taps_ct); the element-wise boundary-tile path of the widest-span
+            // instantiation keeps the rolled loop (register budget: it would spill 3 registers)
+            constexpr bool CT = K9 && !(MT == 128 && NJ == 9 && std::is_same<typename std::remove_reference<decltype(bx)>::type, BStage<NJ>>::value);
+            ws1.issue(wbase);
             bx.issue(seg_base, p.C, cs, 0, wave);
             int c0 = 0;
             unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;   // diagnostic phase sums (p.stamps only)
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                 if (p.stamps) tq = __builtin_amdgcn_s_memtime();
                 __syncthreads();                       // previous chunk's LDS reads are done
                 if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
-                ws.commit(Wl);
+                ws1.commit(Wl);
                 bx.commit(Bl, p.ldb, wave);
                 __syncthreads();
                 if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
@@ -152,24 +162,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                     const int cn = c0 + KC, t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
                     if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
+                    for (int j = 0; j < 3; ++j) ws1.issue_slot(j, wnext);
                     bx.template issue_third<0>(seg_base, p.C, cs, cn, wave);
                     // raised priority while in an MFMA segment: this wave then wins issue arbitration against the
                     // SIMD partner's commit / load-issue phase (+2 % measured)
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
-                    mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 0, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    else mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
                     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-                    for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
+                    for (int j = 3; j < 6; ++j) ws1.issue_slot(j, wnext);
                     bx.template issue_third<1>(seg_base, p.C, cs, cn, wave);
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
-                    if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 3, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    else if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
                     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-                    for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
+                    for (int j = 6; j < 9; ++j) ws1.issue_slot(j, wnext);
                     bx.template issue_third<2>(seg_base, p.C, cs, cn, wave);
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
-                    if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 6, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    else if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
                     __builtin_amdgcn_s_setprio(0);
                 }
                 if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph3 += t - tq; tq = t; }
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                 o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3;
             }
             __syncthreads();                           // peeled last chunk
-            ws.commit(Wl);
+            ws1.commit(Wl);
             bx.commit(Bl, p.ldb, wave);
             __syncthreads();
         };
@@ -354,6 +367,9 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     void (*kern)(TcnParams) =
         big ? (nj <= 6 ? tcn_stage_kernel<128, 6> : tcn_stage_kernel<128, 9>)
             : (nj <= 6 ? tcn_stage_kernel<64, 6> : nj <= 9 ? tcn_stage_kernel<64, 9> : tcn_stage_kernel<64, 14>);
+    if (k == 9 && !csk_diag_flag("CSK_TCN_NOK9"))     // the 9-tap form with straight-line 3-tap MFMA segments
+        kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true> : tcn_stage_kernel<128, 9, true>)
+                   : (nj <= 6 ? tcn_stage_kernel<64, 6, true> : nj <= 9 ? tcn_stage_kernel<64, 9, true> : tcn_stage_kernel<64, 14>);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -351,7 +351,7 @@ class CoStGcnOracle:
     (N, C, V, M) and returns logits (N, classes) on the steps where the whole stack emits, else None.
     The temporal average pool is ``AvgPool1d(pool_size, stride 1)`` over the emitted layer-10
     features with a zero-initialised window of pool_size-1 entries and a fixed divisor
-    (count_include_pad); it emits once pool_size-1-pool_padding features have been seen.
+    (count_include_pad); it emits from the (pool_size - pool_padding)-th feature on.
     """
 
     def __init__(self, sd: Dict[str, Tensor], c_in: int = 3, pool_size: int = 75, pool_padding: int = 19):

@@ -251,6 +251,32 @@ def generate():
     # G9 -- CoModelBase.map_state_dict (models/base.py:200-224), the reference's regular -> continual key map: pure
     #       string code, executed UNBOUND on a stub nn.Module whose state_dict keys are the continual key layout
     out["g9_key_map"] = _key_map(R)
+    # G10 -- aggregate_preds (scripts/multi_stream_eval.py:33-42), the reference's own multi-stream logit fusion, executed
+    #        under the same name-only stubs: np.add / np.maximum over 1-4 streams, 2-D (N, classes) and 3-D (N, classes,
+    #        steps) predictions (the 3-D rule ``preds[:, :, 0]`` is multi_stream_eval.py:56-57, applied by the caller)
+    out["g10_fusion"] = _fusion(R)
+    return out
+
+
+def _fusion(R):
+    import importlib.util
+    sys.modules["ride"].metrics = types.ModuleType("ride.metrics")
+    sys.modules["ride.metrics"] = sys.modules["ride"].metrics
+    sys.modules["ride.metrics"].topk_accuracies = lambda *a, **k: None          # a name only: never called here
+    spec = importlib.util.spec_from_file_location("ref_multi_stream_eval", os.path.join(REF, "scripts", "multi_stream_eval.py"))
+    mse = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mse)
+    rng = np.random.default_rng(1010)
+    out = {}
+    for dims, shape in (("2d", (37, 60)), ("3d", (11, 60, 5))):
+        preds = [rng.standard_normal(shape).astype(np.float32) for _ in range(4)]
+        preds[1][3, 7] = preds[0][3, 7]                                 # a tie between streams
+        preds[2][5] = np.float32(-0.0) if dims == "2d" else preds[2][5]  # signed zeros under maximum / add
+        for i, pr in enumerate(preds):
+            out[f"{dims}/pred{i}"] = pr
+        for n in (1, 2, 3, 4):
+            out[f"{dims}/add{n}"] = mse.aggregate_preds(preds[:n], np.add)
+            out[f"{dims}/maximum{n}"] = mse.aggregate_preds(preds[:n], np.maximum)
     return out
 
 

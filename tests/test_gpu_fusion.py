@@ -28,6 +28,21 @@ def test_fusion_and_topk(n_streams, method, steps):
     assert np.allclose(accs, o.topk_accuracies_np(want, targets), atol=1e-7)
 
 
+@pytest.mark.parametrize("dims", ["2d", "3d"])
+def test_fusion_equals_the_reference_fixture_g10(dims):
+    """csk_fuse_rank_f32 against G10 = outputs of the reference's own aggregate_preds (scripts/multi_stream_eval.py:33-42,
+    executed by tests/golden/make_golden.py): bit-exact for add and maximum over 1-4 streams, 2-D and 3-D predictions."""
+    from tests.helpers import load_golden
+    a, _ = load_golden("g10_fusion")
+    dev = [torch.from_numpy(a[f"{dims}/pred{i}"]).to(DEV) for i in range(4)]
+    for n in (1, 2, 3, 4):
+        for name in ("add", "maximum"):
+            want = a[f"{dims}/{name}{n}"]
+            want = want[:, :, 0] if want.ndim == 3 else want
+            got = pkg.fusion.aggregate_preds(dev[:n], name).cpu().numpy()
+            assert got.shape == want.shape and np.array_equal(got, want), (dims, name, n)
+
+
 def test_fusion_errors():
     a = torch.rand(4, 60, device=DEV)
     with pytest.raises(AssertionError):

@@ -112,6 +112,17 @@ def test_bench_two_ranks_toy_sizes():
     assert d["ranks_seen"] == 1 and d["collective_backend"] == "gloo"
     assert d["value"] > 0 and d["costgcn_online"]["value"] > 0 and d["costgcn_online"]["streams_per_gpu"] == 6
     assert "agcn_kinetics" not in d          # the config-4 side numbers are per GPU, reported at N = 1 only
+    # whole-job work is priced against n_gpus x one GPU's peak in every leg: no fraction can reach 1 (round-4 review: at
+    # N = 8 the accounting would have printed ~6.0)
+    for rc in (d["roofline_config"], d["config5"]["roofline_config"], d["costgcn_online"]["roofline_config"]):
+        assert rc["n_gpus"] == 2 and 0 < rc["frac"] < 1 and 0 < rc["frac_alg"] < 1, rc
+    assert 0 < d["costgcn_online"]["throughput_mode"]["roofline_config_frac"] < 1
+    assert 0 < d["roofline"]["frac"] < 1 and 0 < d["config5"]["roofline"]["frac"] < 1
+    # one row per rank with the device it ran on and its own clock; the two gloo ranks share the one GPU here
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["ms_per_step"] > 0 and r["device_uuid"] for r in pr)
+    assert len({r["device_uuid"] for r in pr}) == d["ranks_seen"] == 1
+    assert max(r["ms_per_step"] for r in pr) <= d["ms_per_step"] * 1.001 + 1e-3
 
 
 def test_bench_self_launch_two_ranks_toy_sizes():
@@ -131,6 +142,7 @@ def test_bench_self_launch_two_ranks_toy_sizes():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     assert d["config5"]["clips_per_gpu"] == 3 and d["config5"]["global_batch"] == 6 and d["config5"]["value"] > 0
     assert d["ranks_seen"] == 1 and d["collective_backend"] == "gloo" and d["value"] > 0
+    assert len(d["per_rank"]) == 2 and 0 < d["roofline_config"]["frac"] < 1 and d["roofline_config"]["n_gpus"] == 2
 
 
 RCCL_WORKER = r'''
@@ -208,3 +220,21 @@ def test_bench_one_rank_rccl_toy_sizes():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["ranks_seen"] == 1 and d["collective_backend"] == "nccl"
     assert d["config5"]["clips_per_gpu"] == 4 and d["config5"]["value"] > 0
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and "error" not in d
+
+
+def test_bench_fails_the_line_when_rccl_ranks_share_a_device():
+    """Two RCCL ranks pinned to ONE device (a launcher that ignores LOCAL_RANK): RCCL refuses the communicator -- or, if it
+    ever came up, bench.py marks the line invalid (`error`, ranks_seen != n_gpus) and exits non-zero.  Either way no valid
+    2-GPU line may come out of a 1-GPU box."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CSK_BENCH_SAME_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--streams", "4",
+           "--steps", "1", "--warmup", "1", "--step-cycles", "1", "--no-cpu-baseline", "--workload", "clip", "--no-split-leg",
+           "--config5-batch", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{"):
+            d = json.loads(ln)
+            assert "error" in d and d["ranks_seen"] != d["n_gpus"]

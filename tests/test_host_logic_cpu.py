@@ -484,3 +484,24 @@ def test_round4_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.csk_input_norm_frames_f32(srcs, dsts, 9, fake, fake, 2, 3, 25, 2, 100, None) == -1 and b"1..8 frames" in lib.csk_last_error()
     assert lib.csk_input_norm_frames_f32(srcs, dsts, 2, fake, fake, 2, 3, 25, 2, 99, None) == -1 and b"bad dims" in lib.csk_last_error()
     assert lib.csk_input_norm_frames_f32(srcs, dsts, 2, fake, fake, 2, 3, 25, 2, 100, None) == -1 and b"null frame" in lib.csk_last_error()
+
+
+def test_roofline_config_prices_n_ranks_against_n_peaks():
+    """bench.py passes the WHOLE JOB's work (per-rank work x world) and the step time; the accounting must price it against
+    world x one MI355X's peak.  With the round-4 driver timing (72.222 ms per batch-256 step) the fraction is 0.75 at one
+    rank AND at eight (weak scaling, same per-rank time) -- it used to print 6.0 at eight (round-4 review, weak item 6)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workmodel
+    fa, fe, by = workmodel.clip_totals(512)
+    one = workmodel.roofline_config(fa, by, 72.222e-3, fe)
+    eight = workmodel.roofline_config(8 * fa, 8 * by, 72.222e-3, 8 * fe, n_gpus=8)
+    assert abs(one["frac"] - 0.7505) < 2e-3 and abs(one["frac_alg"] - 0.7775) < 2e-3
+    assert eight["frac"] == one["frac"] and eight["frac_alg"] == one["frac_alg"] and 0 < eight["frac"] < 1
+    assert eight["n_gpus"] == 8 and eight["peak_tflops"] == round(8 * workmodel.PEAK_F32_MFMA_TFLOPS, 1)
+    assert abs(eight["achieved_tflops_per_gpu"] - one["achieved_tflops"]) < 0.02
+    with pytest.raises(ValueError):
+        workmodel.roofline_config(fa, by, 1.0, fe, n_gpus=0)
+    # the online leg: 1024 streams, 4-frame cycle at the round-4 rate (4.12 ms per cycle) -> 0.70 at any N
+    sa, se, sb = workmodel.step_totals(2048, 4)
+    assert abs(workmodel.roofline_config(8 * sa, 8 * sb, 4.12e-3, 8 * se, n_gpus=8)["frac"] - workmodel.roofline_config(sa, sb, 4.12e-3, se)["frac"]) < 1e-9

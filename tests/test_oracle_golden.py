@@ -174,3 +174,18 @@ def test_committed_fixtures_verify_against_the_reference():
     out = subprocess.run([sys.executable, script, "--verify"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "all committed fixtures verified against the reference: 0.0" in out.stdout
+
+
+@pytest.mark.parametrize("dims", ["2d", "3d"])
+def test_g10_fusion_oracle_equals_the_reference_aggregate_preds(dims):
+    """G10: outputs of the reference's own ``aggregate_preds`` (scripts/multi_stream_eval.py:33-42) -- the oracle's fold must
+    reproduce them bit for bit (for 3-D predictions the reference's caller then keeps ``[:, :, 0]``, :56-57)."""
+    a, _ = load_golden("g10_fusion")
+    preds = [a[f"{dims}/pred{i}"] for i in range(4)]
+    for n in (1, 2, 3, 4):
+        for name, fn in (("add", np.add), ("maximum", np.maximum)):
+            want = a[f"{dims}/{name}{n}"]
+            want = want[:, :, 0] if want.ndim == 3 else want
+            got = o.fuse_preds(preds[:n], fn)
+            assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dims, name, n)
+            assert np.array_equal(np.signbit(got), np.signbit(want))            # -0.0 / +0.0 as the reference leaves them

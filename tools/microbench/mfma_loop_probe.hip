@@ -2,6 +2,7 @@
 // kernels, at 2 waves/SIMD (two 256-thread workgroups per CU), against variants.  hipcc --offload-arch=gfx950.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -464,11 +465,24 @@ template <int L> double run_struct8(int chunks, int blocks) {
     return flops / (ms * 1e-3) / 1e12;
 }
 
+// operands of the struct variants: zeros as in rounds 3-4 (default) or random (argv[1] = 1: the chip holds a lower clock on
+// random data, MI355X_MICROARCH.md DVFS note) -- the loader-wave probe of round 5 is compared under the same setting
+__global__ void fill_kernel(float *p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (float)(h & 0xffff) * (1.f / 65536.f) - 0.5f;
+    }
+}
+static int g_random = 0;
 template <int L, int OCC = 2> double run_struct(int chunks, int blocks, size_t lds_extra = 0) {
     float *out, *gw, *gb;
     hipMalloc(&out, (size_t)blocks * 256 * 4);
     hipMalloc(&gw, (size_t)32 * 9216 * 4 + 65536); hipMemset(gw, 0, (size_t)32 * 9216 * 4 + 65536);
     hipMalloc(&gb, (size_t)blocks * 65536 * 4 + (1 << 20)); hipMemset(gb, 0, (size_t)blocks * 65536 * 4 + (1 << 20));
+    if (g_random) {
+        hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, gw, (size_t)32 * 9216 + 16384);
+        hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, gb, (size_t)blocks * 65536 + (1 << 18));
+    }
     const size_t lds = (TAPS * KC * MT + KC * LDB) * 4 + lds_extra;
     hipFuncSetAttribute((const void *)struct_kernel<L, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -496,8 +510,14 @@ template <int V> double run(int chunks, int blocks, size_t lds_extra = 0) {
     const double flops = (double)blocks * 4 /*waves*/ * chunks * TAPS * (KC / 2) * 4 * 4096.0;
     return flops / (ms * 1e-3) / 1e12;
 }
-int main() {
+int main(int argc, char **argv) {
     const int chunks = 64, blocks = 512 * 6;     // 2 workgroups per CU resident, 6 rounds
+    if (argc > 1) g_random = atoi(argv[1]);
+    if (argc > 2) {                              // short form: the four struct levels only
+        printf("operands %s: struct 0 / 1 / 2 / 3 = %.1f / %.1f / %.1f / %.1f TFLOP/s\n", g_random ? "random" : "zeros", run_struct<0>(chunks, blocks),
+               run_struct<1>(chunks, blocks), run_struct<2>(chunks, blocks), run_struct<3>(chunks, blocks));
+        return 0;
+    }
     printf("variant 0 (as shipped: LDS + pipelined reads + fences): %.1f TFLOP/s\n", run<0>(chunks, blocks));
     printf("variant 1 (LDS, compiler-scheduled):                    %.1f TFLOP/s\n", run<1>(chunks, blocks));
     printf("variant 2 (register operands, no LDS):                  %.1f TFLOP/s\n", run<2>(chunks, blocks));

@@ -88,22 +88,32 @@ def step_totals(n_skel, frames=4, V=25, c_in=3, adaptive=False):
             n_skel * sum(l["bytes"] for l in ls))
 
 
-def roofline_config(flops_alg, bytes_alg, t_measured_s, flops_exec=None):
+def roofline_config(flops_alg, bytes_alg, t_measured_s, flops_exec=None, n_gpus=1):
     """SURVEY 8d / BASELINE.md 3: t_MFMA, t_HBM, t_roof = max, fraction = t_roof / t_measured.
+    `flops_alg`, `flops_exec`, `bytes_alg` are the work of the WHOLE JOB in the measured time (all `n_gpus` ranks) and are
+    priced against the job's peak, `n_gpus` x one MI355X (157.3 TFLOP/s fp32 MFMA, 8 TB/s HBM): a weak-scaling run that
+    scales perfectly keeps the N = 1 fraction at every N, and no fraction can exceed 1.
     `frac` (the headline) prices only the FLOPs the kernels EXECUTE (`flops_executed`: the sparse GCN kernel skips the
     zeros of the skeleton adjacency); `frac_alg` is the same with SURVEY 8d's accounting, which credits the dense
     3 * V aggregation MACs per element (3.5 % of the ST-GCN total that is never executed)."""
+    if n_gpus < 1:
+        raise ValueError("roofline_config: n_gpus must be >= 1")
     fe = flops_alg if flops_exec is None else flops_exec
-    t_mfma_alg = flops_alg / (PEAK_F32_MFMA_TFLOPS * 1e12)
-    t_mfma = fe / (PEAK_F32_MFMA_TFLOPS * 1e12)
-    t_hbm = bytes_alg / (PEAK_HBM_TBS * 1e12)
+    peak_f = PEAK_F32_MFMA_TFLOPS * 1e12 * n_gpus
+    peak_b = PEAK_HBM_TBS * 1e12 * n_gpus
+    t_mfma_alg = flops_alg / peak_f
+    t_mfma = fe / peak_f
+    t_hbm = bytes_alg / peak_b
     t_roof = max(t_mfma, t_hbm)
-    return dict(flops_alg=flops_alg, flops_executed=fe, bytes_alg=bytes_alg, t_mfma_ms=round(t_mfma * 1e3, 4),
+    return dict(flops_alg=flops_alg, flops_executed=fe, bytes_alg=bytes_alg, n_gpus=n_gpus,
+                peak_tflops=round(PEAK_F32_MFMA_TFLOPS * n_gpus, 1), peak_hbm_tbs=round(PEAK_HBM_TBS * n_gpus, 1),
+                t_mfma_ms=round(t_mfma * 1e3, 4),
                 t_hbm_ms=round(t_hbm * 1e3, 4), t_roof_ms=round(t_roof * 1e3, 4), t_measured_ms=round(t_measured_s * 1e3, 4),
                 bound="mfma" if t_mfma >= t_hbm else "hbm", frac=round(t_roof / t_measured_s, 4),
                 frac_executed=round(t_roof / t_measured_s, 4),
                 frac_alg=round(max(t_mfma_alg, t_hbm) / t_measured_s, 4),
                 achieved_tflops=round(fe / t_measured_s / 1e12, 2),
+                achieved_tflops_per_gpu=round(fe / t_measured_s / 1e12 / n_gpus, 2),
                 achieved_hbm_alg_tbs=round(bytes_alg / t_measured_s / 1e12, 3))
 
 
