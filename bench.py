@@ -397,6 +397,77 @@ def run_latency(pkg, dev, cpu_step, stream_counts=(1, 16), frames=400):
             "note": "frames 1-3 of a stride cycle run fewer blocks than the 4th (strides 2, 2): p99 is the predicting frame"}
 
 
+def run_clip_latency(pkg, dev, cpu, batches=(1, 8), forwards=200, split_k=4):
+    """Small-batch clip inference (the reference's own CPU protocol is batch 1: scripts/benchmark_all_ntu60.py:17): the whole
+    StGcn forward at batch 1 and 8, every forward host-synchronised (a sample = submit -> logits ready), p50 / p99 over
+    `forwards` forwards -- eager (Python launches every kernel) and as a replayed hipGraph (one launch per forward) -- in the
+    default mode and in the latency mode (StGcn.set_latency_mode: split-K on every stage launch; the factor depends on the
+    layer only, never on the batch).  `pipelined_ms` = graph replays back to back without per-forward synchronisation."""
+    import statistics
+    net = pkg.StGcn(pkg.ntu_graph().A, input_shape=(NTU["C"], NTU["T"], NTU["V"], NTU["M"]), num_classes=NTU["classes"]).eval()
+    randomise_(net, seed=0)
+    net = net.to(dev)
+
+    def pct(ts, q):
+        ts = sorted(ts)
+        return round(ts[int(q * (len(ts) - 1))] * 1e3, 4)
+
+    rows = []
+    for b in batches:
+        x = torch.rand((b, NTU["C"], NTU["T"], NTU["V"], NTU["M"]), device=dev, generator=torch.Generator(device=dev).manual_seed(40 + b))
+        row = {"batch": b}
+        ref = None
+        for mode, sk in (("default", 0), ("latency_mode", split_k)):
+            net.set_latency_mode(sk)
+            for _ in range(3):
+                out = net(x)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.clone()
+            eager = []
+            for _ in range(forwards):
+                t0 = time.perf_counter()
+                out = net(x)
+                torch.cuda.synchronize()
+                eager.append(time.perf_counter() - t0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                gout = net(x)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            graph = []
+            for _ in range(forwards):
+                t0 = time.perf_counter()
+                g.replay()
+                torch.cuda.synchronize()
+                graph.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for _ in range(forwards):
+                g.replay()
+            torch.cuda.synchronize()
+            piped = (time.perf_counter() - t0) / forwards
+            assert bool(torch.isfinite(gout).all()) and torch.equal(gout, out)
+            row[mode] = {"split_k": sk, "eager_ms_p50": pct(eager, 0.5), "eager_ms_p99": pct(eager, 0.99),
+                         "graph_ms_p50": pct(graph, 0.5), "graph_ms_p99": pct(graph, 0.99), "pipelined_ms": round(piped * 1e3, 4),
+                         "clips_per_s_graph_p50": round(b / statistics.median(graph), 1),
+                         "max_abs_logit_diff_vs_default": float((out - ref).abs().max())}
+            del g, gout
+        fa, fe, by = workmodel.clip_totals(b * NTU["M"])
+        best = min(row["default"]["graph_ms_p50"], row["latency_mode"]["graph_ms_p50"])
+        row["roofline_config_frac_best_graph_p50"] = workmodel.roofline_config(fa, by, best * 1e-3, fe)["frac"]
+        rows.append(row)
+        del x
+    net.set_latency_mode(0)
+    del net
+    gc.collect()
+    torch.cuda.empty_cache()
+    cpu_b1 = cpu["runs"].get("batch1") if cpu else None
+    return {"mode": "StGcn clip forward, NTU-60 shape, fp32, host-synchronised per forward", "forwards_timed": forwards,
+            "per_batch": rows, "cpu_oracle_batch1_ms": round(1e3 / cpu_b1, 3) if cpu_b1 else None,
+            "cpu_oracle_batch1_clips_per_s": cpu_b1}
+
+
 def load_traffic(name="traffic_tcn_stage.json", batch=None, streams=None):
     """Per-launch HBM bytes of the dominant kernel from the COMMITTED PMC summaries (profiles/; separate rocprofv3 --pmc
     passes of tools/profile_r05.sh condensed by tools/summarize_pmc.py -- not measured by this run, the line says so under
@@ -496,6 +567,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the 1- and 16-stream per-frame latency leg of the online workload")
     ap.add_argument("--latency-frames", type=int, default=400, help="frames timed per stream count by the latency leg")
+    ap.add_argument("--no-clip-latency-leg", action="store_true", help="skip the batch-1 / batch-8 clip latency leg (N = 1 only)")
+    ap.add_argument("--clip-latency-forwards", type=int, default=200, help="forwards timed per batch size and mode by the clip latency leg")
     ap.add_argument("--cpu-budget", type=float, default=50.0, help="seconds of CPU work the configs[1]/[2] cpu_baseline legs may take in all")
     ap.add_argument("--cpu-budget-config4", type=float, default=14.0, help="seconds of CPU work for the two configs[3] cpu_baseline legs")
     args = ap.parse_args()
@@ -684,6 +757,8 @@ def main():
                               "note": "6 bf16 MFMA products per fp32 product: executed FLOPs = 6 x the fp32-equivalent; peak 2.5 PFLOP/s dense bf16"},
                 "fp32_path_tcn_stage_avg_launch_ms": round(avg_launch_s * 1e3, 4),
                 "scope": "clip kernels only (csk_tcn_stage_bf16x3, csk_gcn_stage_bf16x3); the continual step kernels stay exact fp32 (DESIGN.md)"}
+        if world == 1 and not args.no_clip_latency_leg:
+            line["clip_latency"] = run_clip_latency(pkg, dev, cpu, forwards=args.clip_latency_forwards)
         if use_dist or not args.no_config5_leg:
             # BASELINE.json configs[4]: batch 8192 over 8 GPUs = 1024 clips per GPU + the RCCL logit all-gather.  Reported
             # beside the 256 / GPU weak-scaling headline (which stays comparable with the N = 1 line); at N = 8 this IS

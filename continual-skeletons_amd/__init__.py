@@ -15,6 +15,7 @@ from .blocks import (  # noqa: F401
     SpatioTemporalBlock,
     TemporalConvolution,
     init_weights,
+    set_clip_latency_mode,
     set_precision,
     unity,
     zero,
@@ -40,5 +41,5 @@ __all__ = [
     "SpatioTemporalBlock", "SpatialGraphConv", "StGcnBlock", "CoStGcnBlock", "StGcn", "CoStGcn",
     "CoGraphConvolution", "CoTemporalConvolution", "CoSpatioTemporalBlock",
     "AdaptiveGraphConvolution", "CoAdaptiveGraphConvolution", "AGcn", "CoAGcn", "init_weights", "zero", "unity",
-    "native", "fusion", "set_precision",
+    "native", "fusion", "set_precision", "set_clip_latency_mode",
 ]

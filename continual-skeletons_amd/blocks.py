@@ -45,19 +45,60 @@ def unity(x):
 # ---- folded-operand cache -------------------------------------------------------------------------
 class _Folded(nn.Module):
     """Mixin: caches the packed device operands and refolds when any parameter/buffer changed
-    (load_state_dict, .to(), in-place edits) -- SURVEY 8b 'Folding must be redone if weights are reloaded'."""
+    (load_state_dict, .to(), in-place edits) -- SURVEY 8b 'Folding must be redone if weights are reloaded'.
+
+    Staleness is checked on EVERY call and exactly, but cheaply: the cache keeps a flat snapshot of where the watched
+    tensors and sub-modules LIVE (owning ``_parameters`` / ``_buffers`` / ``_modules`` dict + name, with the tensor's
+    identity, storage pointer and version counter); re-reading those dict slots costs ~0.15 us each, where walking
+    ``parameters()`` / ``buffers()`` cost 35-57 us per module -- 0.94 ms of host time per StGcn forward, more than a
+    batch-1 clip takes on the GPU.  A replaced Parameter or buffer, a swapped / added / removed sub-module, an in-place
+    edit (version counter) and ``p.data = ...`` (storage pointer) are all seen on the next call."""
+
+    def _watched(self):
+        """Modules whose tensors the packed operands are folded from (default: this module and everything below it)."""
+        return [self]
+
+    def _snapshot(self):
+        tensors, modules, seen = [], [(self._modules, tuple(self._modules.items()))], set()   # own slots: a swapped child
+        for root in self._watched():
+            for m in root.modules():
+                if id(m) in seen:
+                    continue
+                seen.add(id(m))
+                for d in (m._parameters, m._buffers):
+                    for name, t in d.items():
+                        tensors.append((d, name, t, None if t is None else t.data_ptr(), None if t is None else t._version))
+                modules.append((m._modules, tuple(m._modules.items())))
+        return tensors, modules
+
+    @staticmethod
+    def _stale(snapshot):
+        tensors, modules = snapshot
+        for d, name, t, ptr, ver in tensors:
+            cur = d.get(name)
+            if cur is not t or (t is not None and (cur._version != ver or cur.data_ptr() != ptr)):
+                return True
+        for d, items in modules:
+            if len(d) != len(items):
+                return True
+            for name, child in items:
+                if d.get(name) is not child:
+                    return True
+        return False
 
     def _fingerprint(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        """(storage pointer, version) of every watched tensor -- the slow, walk-everything form (kept for tests and tools)."""
+        ts = [t for root in self._watched() for t in list(root.parameters()) + list(root.buffers())]
+        return tuple((t.data_ptr(), t._version) for t in ts)
 
     def _packed_ops(self, device):
-        fp = (self._fingerprint(), str(device))
         cache = self.__dict__.get("_fold_cache")
-        if cache is None or cache[0] != fp:
+        device = str(device)
+        if cache is None or cache[0] != device or self._stale(cache[2]):
             # "*_host" entries are read by the C ABI on the host (e.g. ell_cnt); everything else lives in HBM
             ops = {k: (v.to(device) if isinstance(v, torch.Tensor) and not k.endswith("_host") else v)
                    for k, v in self._fold().items()}
-            self.__dict__["_fold_cache"] = cache = (fp, ops)
+            self.__dict__["_fold_cache"] = cache = (device, ops, self._snapshot())
         return cache[1]
 
     def refold(self):
@@ -97,6 +138,50 @@ def set_precision(module: nn.Module, precision: str = "f32") -> nn.Module:
         if isinstance(m, SpatioTemporalBlock) or type(m) is GraphConvolution:
             m.precision = precision
             m.refold()
+    return module
+
+
+_SPLIT_SCRATCH = {}
+
+
+def split_scratch(device, floats: int) -> torch.Tensor:
+    """Partial-sum buffer of the split-K launches (clip latency mode): ONE growing buffer per (device, HIP stream) --
+    launches on a stream are ordered, so every layer can reuse it.  Under hipGraph capture the buffer must exist already
+    (run one eager forward first, as graph capture needs anyway)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _SPLIT_SCRATCH.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(int(floats), device=device, dtype=torch.float32)
+        _SPLIT_SCRATCH[key] = buf
+    return buf
+
+
+def set_clip_latency_mode(module: nn.Module, split_k: int = 4, gcn_split_k: int = None) -> nn.Module:
+    """Small-batch clip inference (the reference's own CPU protocol is batch 1, scripts/benchmark_all_ntu60.py:17).
+
+    At a few clips a stage launch is a few dozen tiles on 256 CUs, each walking its whole K loop alone (a 256-channel
+    temporal conv: 2 x 15 x 2 = 60 workgroups x 288 K-chunks at batch 1).  With ``split_k`` > 1 every 9 x 1 temporal conv
+    and every plain graph conv (>= 16 input channels) below ``module`` cuts its K loop into ``split_k`` channel ranges
+    computed by separate workgroups (csk_tcn_stage_splitk_f32 / csk_gcn_stage_splitk_f32) and summed in split order by a
+    second launch.  The factor is a function of ``split_k`` and the layer's channel count ONLY -- never of the batch -- so
+    a clip's logits do not depend on how many clips share the forward; against the default mode they differ by the
+    summation order (parity with the oracle within the same 1e-4).  ``split_k`` <= 1 switches it off.  Costs throughput
+    at large batches (partial sums travel through HBM): use it for N * M of up to a few dozen sequences.
+    ``gcn_split_k`` (default: ``split_k``) sets the graph convs' factor separately."""
+    gcn_split_k = split_k if gcn_split_k is None else gcn_split_k
+    for v in (split_k, gcn_split_k):
+        if not isinstance(v, int) or v < 0 or v > 32:
+            raise ValueError("split_k must be an integer in [0, 32]")
+    hit = False
+    for m in module.modules():
+        if isinstance(m, SpatioTemporalBlock):
+            m.clip_split_k = split_k
+            hit = True
+        elif type(m) is GraphConvolution:
+            m.clip_split_k = gcn_split_k
+            hit = True
+    if not hit:
+        raise ValueError("no SpatioTemporalBlock / GraphConvolution below this module: nothing to set")
     return module
 
 
@@ -159,8 +244,22 @@ class GraphConvolution(_Folded):
                 self.out_channels, t, v, ops["res_mode"], native.stream_of(x))
             native.check(rc, "csk_gcn_stage_bf16x3")
             return y
+        ks = self._clip_ksplit()
+        if ks > 1:
+            self.stage(x, y, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v),
+                       ksplit=ks, partial=split_scratch(x.device, ks * n * self.out_channels * t * v))
+            return y
         gcn_stage(x, y, ops, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v))
         return y
+
+    clip_split_k = 0       # set_clip_latency_mode: channel ranges per tile of the clip forward (0 / 1: off)
+
+    def _clip_ksplit(self) -> int:
+        """Split factor of the clip forward: min(clip_split_k, 8-channel chunks of the K loop) for plain graph convs with
+        >= 16 input channels -- a function of (clip_split_k, C_in) only."""
+        if self.clip_split_k <= 1 or type(self) is not GraphConvolution or self.in_channels < 16:
+            return 1
+        return max(1, min(self.clip_split_k, -(-self.in_channels // 8)))
 
     def stage(self, x, y, n_seg, frames, x_strides, y_strides, ksplit=1, partial=None):
         """Launch on explicit views/strides (used by the continual engine on its channel-major rings).  ``ksplit`` > 1
@@ -215,8 +314,9 @@ class TemporalConvolution(_Folded):
 
 
 def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=None, w_res=None, res_off=0, out=None,
-              split=False):
-    """csk_tcn_stage_f32, or with split=True csk_tcn_stage_bf16x3 (w / w_res are then the split operand images)."""
+              split=False, ksplit=1):
+    """csk_tcn_stage_f32, or with split=True csk_tcn_stage_bf16x3 (w / w_res are then the split operand images), or with
+    ksplit > 1 csk_tcn_stage_splitk_f32 (clip latency mode: K loop cut into channel ranges, partial sums in split order)."""
     n, c, t_in, v = y.shape
     if t_in + 2 * pad < k:
         raise RuntimeError(f"temporal extent {t_in} (+2*{pad}) shorter than kernel {k}")
@@ -226,6 +326,14 @@ def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=No
     elif tuple(out.shape) != (n, c_out, t_out, v) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != y.device:
         raise RuntimeError(f"out must be a contiguous float32 {(n, c_out, t_out, v)} tensor on {y.device}")
     c_res, t_res = (x_res.shape[1], x_res.shape[2]) if x_res is not None else (0, 0)
+    if ksplit > 1 and not split:
+        part = split_scratch(y.device, ksplit * n * c_out * t_out * v)
+        rc = native.lib().csk_tcn_stage_splitk_f32(
+            native.ptr(y), native.ptr(w), native.ptr(x_res), native.ptr(w_res), native.ptr(bias), native.ptr(out),
+            n, c, c_out, t_in, v, k, stride, pad, res_mode, c_res, t_res, res_off, int(relu), ksplit, native.ptr(part),
+            native.stream_of(y))
+        native.check(rc, "csk_tcn_stage_splitk_f32")
+        return out
     fn = native.lib().csk_tcn_stage_bf16x3 if split else native.lib().csk_tcn_stage_f32
     rc = fn(native.ptr(y), native.ptr(w), native.ptr(x_res), native.ptr(w_res), native.ptr(bias), native.ptr(out),
             n, c, c_out, t_in, v, k, stride, pad, res_mode, c_res, t_res, res_off, int(relu), native.stream_of(y))
@@ -264,6 +372,10 @@ class SpatioTemporalBlock(_Folded):
         )
 
     precision = "f32"      # or "bf16x3" (opt-in, set_precision): arithmetic of the temporal conv / residual conv kernels
+    clip_split_k = 0       # set_clip_latency_mode: channel ranges per tile of the clip forward's temporal conv (0 / 1: off)
+
+    def _watched(self):    # the tail's operands are folded from the temporal conv and the residual conv; the graph conv keeps its own cache
+        return [m for m in (self.tcn, self.residual) if isinstance(m, nn.Module)]
 
     def _fold(self):
         sd = self.state_dict()
@@ -291,8 +403,9 @@ class SpatioTemporalBlock(_Folded):
         if self.precision == "bf16x3":
             return tcn_stage(y, ops["w_split"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
                              res_mode=mode, x_res=xr, w_res=ops["w_res_split"], res_off=shrink, out=out, split=True)
+        ks = max(1, min(self.clip_split_k, -(-ops["c"] // 8))) if (self.clip_split_k > 1 and ops["k"] == 9) else 1
         return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
-                         res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out)
+                         res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out, ksplit=ks)
 
 
 def tcn_step_launch(*args):

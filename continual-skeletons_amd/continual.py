@@ -514,9 +514,8 @@ class CoStGcn(_Folded):
         s, t = fold.fold_data_bn({k: v for k, v in nn.Module.state_dict(self).items() if k.startswith("data_bn.")})
         return dict(scale=s, shift=t)
 
-    def _fingerprint(self):
-        ts = list(self.data_bn.parameters()) + list(self.data_bn.buffers())
-        return tuple((t.data_ptr(), t._version) for t in ts)
+    def _watched(self):
+        return [self.data_bn]
 
     # ---- state slab --------------------------------------------------------------------------------
     def _bind(self, n, device):

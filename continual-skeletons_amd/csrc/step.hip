@@ -167,21 +167,21 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
             for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<0>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            if (k9) mfma_taps_pipe<MT, 3>(Wl, Bl, 0, NP, KC * NP, offA, off0, off1, kh, acc);
+            if (k9) mfma_taps_ct<MT, 3>(Wl, Bl, 0, NP, KC * NP, offA, off0, off1, kh, acc);
             else mfma_taps<MT>(Wl, Bl, 0, t1, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<1>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            if (k9) mfma_taps_pipe<MT, 3>(Wl, Bl, 3, NP, KC * NP, offA, off0, off1, kh, acc);
+            if (k9) mfma_taps_ct<MT, 3>(Wl, Bl, 3, NP, KC * NP, offA, off0, off1, kh, acc);
             else if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
             rs.template issue_third<2>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
-            if (k9) mfma_taps_pipe<MT, 3>(Wl, Bl, 6, NP, KC * NP, offA, off0, off1, kh, acc);
+            if (k9) mfma_taps_ct<MT, 3>(Wl, Bl, 6, NP, KC * NP, offA, off0, off1, kh, acc);
             else if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
         }

@@ -32,10 +32,12 @@ struct TcnParams {
     int fast_epi;                 // row strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
     int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
     int vec_stage;                // 16-byte activation staging on interior tiles (diagnostic CSK_TCN_NOVEC=1 turns it off)
+    int ksplit, cper;             // split-K form (csk_tcn_stage_splitk_f32): ksplit channel ranges of cper channels per tile,
+    float *part;                  // raw partial sums part[(seg * ksplit + ks)][Cout][Tout * V]; ksplit == 1: off
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
 
-template <int MT, int NJ, bool K9 = false>
+template <int MT, int NJ, bool K9 = false, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams p) {
     constexpr int OCC = 2;   // 3 (epilogue operands loaded after the K loop, <= 168 registers) was measured: the K loop's
                              // staging registers then spill and the stage runs 13-19 % slower
@@ -51,7 +53,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     // work item -> (m-tile fastest: shares the activation tile; then position tile: shares halos; then segment)
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int m0 = (int)(wid % p.mtiles) * MT, q0 = (int)((wid / p.mtiles) % p.qtiles) * p.nt;
-    const int seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int segks = (int)(wid / (p.mtiles * p.qtiles));
+    // SPLIT (few-tile launches, csk_tcn_stage_splitk_f32): this workgroup walks the channel range [cb, cb + cper) of its tile
+    // and stores raw partial sums; bias, identity residual and ReLU belong to tcn_reduce_kernel
+    const int seg = SPLIT ? segks / p.ksplit : segks, ks = SPLIT ? segks % p.ksplit : 0;
+    const int cb = SPLIT ? ks * p.cper : 0;
+    const int Cl = SPLIT ? min(p.C - cb, p.cper) : p.C;               // real channels of the range (>= 1 by construction)
+    const int CpadL = SPLIT ? min(p.Cpad - cb, p.cper) : p.Cpad;
     const int V = p.V, Q = p.Tout * V;
     const int qend = min(q0 + p.nt, Q);          // p.nt == NT unless the staged span had to be narrowed (large stride * V)
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
@@ -80,10 +88,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     // epilogue operands: 32 biases + (identity residual) 64 block-input values per lane.  They are loaded
     // UNDER THE LAST CHUNK'S MFMAs (the K loops are peeled by one iteration; the staging registers are dead
     // there), unconditionally (clamped indices, bias padded to Mpad), so the epilogue itself is stores only.
-    float *oseg = p.out + (int64_t)seg * p.Cout * Q;
+    float *oseg = SPLIT ? p.part + (int64_t)segks * p.Cout * Q : p.out + (int64_t)seg * p.Cout * Q;
     const float *rseg = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
     const int64_t rcs = (int64_t)p.Tres * V;
-    const bool ident = p.res_mode == CSK_RES_IDENTITY;
+    const bool ident = !SPLIT && p.res_mode == CSK_RES_IDENTITY;
     float bv[2][16], rv[2][2][16];
     // Rows of this wave: rbase + mi*32 + (g & 3) + 8*(g >> 2) (+ 4*kh in the accumulator layout); everything but the
     // lane's own offset is wave-uniform.  On full tiles (all MT rows exist) the row base pointers are formed on the
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     auto load_half = [&](int mi) {
         if (full) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) bv[mi][g] = ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
+            for (int g = 0; g < 16; ++g) bv[mi][g] = SPLIT ? 0.f : ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             }
         } else {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) bv[mi][g] = p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
+            for (int g = 0; g < 16; ++g) bv[mi][g] = SPLIT ? 0.f : p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int qc = min(q0 + wn * 64 + ni * 32 + l31, qend - 1);
@@ -123,16 +131,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             }
         }
     };
-    const bool conv_res = p.res_mode == CSK_RES_CONV;
+    const bool conv_res = p.res_mode == CSK_RES_CONV && ks == 0;       // split-K: the residual conv rides in split 0
     // ---- phase 1: k x 1 temporal conv over y.  The loop is written once over the activation-staging type: tiles whose
     // whole staged span lies inside the row (no zero padding to apply: all but the 1-2 tiles at either end of a
     // sequence) stage with 16-byte loads / LDS writes (BStage4), the others element-wise with clamp + select (BStage).
     {
         const int fa = p.stride * ta - p.pad;
         const int span = (p.stride * (tb - ta) + p.K) * V;
-        const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V;
         const int64_t cs = (int64_t)p.Tin * V;
-        const float *wbase = p.w + m0;
+        const float *seg_base = p.y + (int64_t)seg * p.C * p.Tin * V + (int64_t)cb * cs;
+        const float *wbase = p.w + m0 + (size_t)cb * p.Mpad;
         // 9-tap chunks: the compact weight staging (offsets of a thread's slots differ by wave-uniform constants)
         using WS9 = typename std::conditional<MT == 128, WStage9x128, WStage9x64>::type;
         typename std::conditional<K9, WS9, WStage<MT> &>::type ws1 = [&]() -> decltype(auto) {
@@ -144,10 +152,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             // instantiation keeps the rolled loop (register budget: it would spill 3 registers)
             constexpr bool CT = K9 && !(MT == 128 && NJ == 9 && std::is_same<typename std::remove_reference<decltype(bx)>::type, BStage<NJ>>::value);
             ws1.issue(wbase);
-            bx.issue(seg_base, p.C, cs, 0, wave);
+            bx.issue(seg_base, Cl, cs, 0, wave);
             int c0 = 0;
             unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;   // diagnostic phase sums (p.stamps only)
-            for (; c0 + KC < p.Cpad; c0 += KC) {
+            for (; c0 + KC < CpadL; c0 += KC) {
                 if (p.stamps) tq = __builtin_amdgcn_s_memtime();
                 __syncthreads();                       // previous chunk's LDS reads are done
                 if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                     if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
 #pragma unroll
                     for (int j = 0; j < 3; ++j) ws1.issue_slot(j, wnext);
-                    bx.template issue_third<0>(seg_base, p.C, cs, cn, wave);
+                    bx.template issue_third<0>(seg_base, Cl, cs, cn, wave);
                     // raised priority while in an MFMA segment: this wave then wins issue arbitration against the
                     // SIMD partner's commit / load-issue phase (+2 % measured)
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
@@ -172,14 +180,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                     for (int j = 3; j < 6; ++j) ws1.issue_slot(j, wnext);
-                    bx.template issue_third<1>(seg_base, p.C, cs, cn, wave);
+                    bx.template issue_third<1>(seg_base, Cl, cs, cn, wave);
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
                     if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 3, p.ldb, V, offA, off[0], off[1], kh, acc);
                     else if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
                     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                     for (int j = 6; j < 9; ++j) ws1.issue_slot(j, wnext);
-                    bx.template issue_third<2>(seg_base, p.C, cs, cn, wave);
+                    bx.template issue_third<2>(seg_base, Cl, cs, cn, wave);
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
                     if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 6, p.ldb, V, offA, off[0], off[1], kh, acc);
                     else if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         for (int g = 0; g < 16; ++g) {
             float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
             float v1 = acc[mi][1][g] + bv[mi][g] + rv[1][mi][g];
-            if (p.relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
+            if (!SPLIT && p.relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
             acc[mi][0][g] = __uint_as_float(sw[0]);        // row rbase + mi*32 + (g&3) + 8(g>>2), this lane's column qb
             acc[mi][1][g] = __uint_as_float(sw[1]);        // row + 4
@@ -294,10 +302,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
-                                 const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,
-                                 int stride, int pad, int res_mode, int c_res, int t_res, int res_off, int relu,
-                                 void *stream) {
+// split-K reduction of the TCN stage: out[seg][co][q] = ReLU?( sum_ks part[seg * ksplit + ks][co][q] (split order) + bias[co]
+// + identity residual x_res[seg][co][(t * stride + res_off) * V + v] ); one thread per 4 consecutive (co, q) of a segment
+__global__ __launch_bounds__(256) void tcn_reduce_kernel(const TcnParams p) {
+    const int Q = p.Tout * p.V;
+    const int64_t n = (int64_t)p.Cout * Q;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int seg = blockIdx.y;
+    if (i0 >= n) return;
+    const float *pp = p.part + (int64_t)seg * p.ksplit * n;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = i0 + 4 <= n && (n & 3) == 0;
+    for (int ks = 0; ks < p.ksplit; ++ks) {
+        if (vec) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(pp + (int64_t)ks * n + i0);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        } else {
+            for (int j = 0; j < 4; ++j) if (i0 + j < n) s[j] += pp[(int64_t)ks * n + i0 + j];
+        }
+    }
+    float *o = p.out + (int64_t)seg * n;
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = i0 + j;
+        if (i >= n) break;
+        const int co = (int)(i / Q), q = (int)(i - (int64_t)co * Q);
+        float v = s[j] + p.bias[co];
+        if (p.res_mode == CSK_RES_IDENTITY) {
+            const int t = div_magic(q, p.vmagic);
+            v += p.xres[((int64_t)seg * p.Cres + co) * p.Tres * p.V + (int64_t)(t * p.stride + p.res_off) * p.V + (q - t * p.V)];
+        }
+        o[i] = p.relu ? relu_nan(v) : v;
+    }
+}
+
+static int tcn_stage_impl(const float *y, const float *w, const float *x_res, const float *w_res,
+                          const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,
+                          int stride, int pad, int res_mode, int c_res, int t_res, int res_off, int relu, int ksplit,
+                          float *partial, void *stream) {
     if (!y || !w || !bias || !out) CSK_FAIL("tcn_stage: null pointer");
     if (n_seg <= 0 || c <= 0 || c_out <= 0 || t_in <= 0 || V < 2 || V > 64) CSK_FAIL("tcn_stage: bad dims");
     if (k < 1 || k > 9 || stride < 1 || pad < 0 || pad >= k) CSK_FAIL("tcn_stage: bad k/stride/pad (k <= 9)");
@@ -310,12 +351,19 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
         if ((t_out - 1) * stride + res_off >= t_res || res_off < 0) CSK_FAIL("tcn_stage: residual frames out of range");
     }
     if ((int64_t)t_in * V >= (1 << 26)) CSK_FAIL("tcn_stage: T*V too large for 32-bit position arithmetic");
+    if (ksplit < 1 || ksplit > 64) CSK_FAIL("tcn_stage: ksplit must be in [1, 64]");
+    if (ksplit > 1 && (!partial || ((uintptr_t)partial & 15))) CSK_FAIL("tcn_stage: split-K needs a 16-byte aligned partial-sum buffer");
+    if (ksplit > 1 && k != 9) CSK_FAIL("tcn_stage: the split-K form is built for the 9-tap conv");
     TcnParams p;
     p.y = y; p.w = w; p.xres = x_res ? x_res : y; p.wres = w_res; p.bias = bias; p.out = out;
     p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.Tin = t_in; p.Tout = t_out; p.V = V; p.K = k; p.stride = stride; p.pad = pad;
     p.res_mode = res_mode; p.Cres = c_res > 0 ? c_res : 1; p.CresPad = round_up(p.Cres, CSK_CPAD);
     p.Tres = t_res > 0 ? t_res : 1; p.res_off = res_off; p.relu = relu; p.vmagic = vmagic_of(V);
+    // split-K: every range owns >= 1 real channel; fewer ranges than asked for if the channel count does not allow more
+    p.cper = round_up((p.Cpad + ksplit - 1) / ksplit, KC);
+    p.ksplit = ksplit > 1 ? (c + p.cper - 1) / p.cper : 1;
+    p.part = partial;
     p.stamps = csk_diag_stamps();
     p.prio = !csk_diag_flag("CSK_NOPRIO");
     p.vec_stage = !csk_diag_flag("CSK_TCN_NOVEC");
@@ -359,8 +407,8 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = t_out * V;
     p.qtiles = (Q + p.nt - 1) / p.nt; p.mtiles = p.Mpad / MT;
-    if ((int64_t)p.qtiles * p.mtiles * n_seg >= (1ll << 31)) CSK_FAIL("tcn_stage: grid too large");
-    dim3 grid(p.qtiles * p.mtiles * n_seg);
+    if ((int64_t)p.qtiles * p.mtiles * n_seg * p.ksplit >= (1ll << 31)) CSK_FAIL("tcn_stage: grid too large");
+    dim3 grid(p.qtiles * p.mtiles * n_seg * p.ksplit);
     // NJ = 64-lane sweeps of the activation staging per row: the smallest instantiation that covers the span (sweeps
     // beyond it re-load and re-commit its last position: wasted load / LDS-write slots).  128x128 tiles of the
     // stride-1 layers need 6 sweeps, not 9: -2.7 % on their tiles.
@@ -370,8 +418,34 @@ extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_
     if (k == 9 && !csk_diag_flag("CSK_TCN_NOK9"))     // the 9-tap form with straight-line 3-tap MFMA segments
         kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true> : tcn_stage_kernel<128, 9, true>)
                    : (nj <= 6 ? tcn_stage_kernel<64, 6, true> : nj <= 9 ? tcn_stage_kernel<64, 9, true> : tcn_stage_kernel<64, 14>);
+    if (p.ksplit > 1) {
+        if (nj > 9) CSK_FAIL("tcn_stage: the split-K form covers activation tiles of <= 576 positions per channel");
+        kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true, true> : tcn_stage_kernel<128, 9, true, true>)
+                   : (nj <= 6 ? tcn_stage_kernel<64, 6, true, true> : tcn_stage_kernel<64, 9, true, true>);
+    }
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, (hipStream_t)stream, p);
+    if (p.ksplit > 1) {
+        if (const int e = (int)hipGetLastError()) return e;
+        const int64_t work = ((int64_t)c_out * Q + 3) / 4;
+        hipLaunchKernelGGL(tcn_reduce_kernel, dim3((unsigned)((work + 255) / 256), n_seg), dim3(256), 0, (hipStream_t)stream, p);
+    }
     return (int)hipGetLastError();
+}
+
+extern "C" int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const float *w_res,
+                                 const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,
+                                 int stride, int pad, int res_mode, int c_res, int t_res, int res_off, int relu,
+                                 void *stream) {
+    return tcn_stage_impl(y, w, x_res, w_res, bias, out, n_seg, c, c_out, t_in, V, k, stride, pad, res_mode, c_res, t_res, res_off, relu,
+                          1, nullptr, stream);
+}
+
+extern "C" int csk_tcn_stage_splitk_f32(const float *y, const float *w, const float *x_res, const float *w_res,
+                                        const float *bias, float *out, int n_seg, int c, int c_out, int t_in, int V, int k,
+                                        int stride, int pad, int res_mode, int c_res, int t_res, int res_off, int relu,
+                                        int ksplit, float *partial, void *stream) {
+    return tcn_stage_impl(y, w, x_res, w_res, bias, out, n_seg, c, c_out, t_in, V, k, stride, pad, res_mode, c_res, t_res, res_off, relu,
+                          ksplit, partial, stream);
 }
 

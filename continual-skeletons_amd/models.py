@@ -42,9 +42,8 @@ class StGcn(_Folded):
         s, t = fold.fold_data_bn({k: v for k, v in self.state_dict().items() if k.startswith("data_bn.")})
         return dict(scale=s, shift=t)
 
-    def _fingerprint(self):   # only the driver's own tensors; blocks keep their own caches
-        ts = list(self.data_bn.parameters()) + list(self.data_bn.buffers())
-        return tuple((t.data_ptr(), t._version) for t in ts)
+    def _watched(self):       # only the driver's own folded tensors; blocks keep their own caches
+        return [self.data_bn]
 
     def input_norm(self, x):
         """(N, C, T, V, M) -> (N*M, C, T, V): permute + data_bn (models/st_gcn/st_gcn.py:49-57)."""
@@ -80,3 +79,8 @@ class StGcn(_Folded):
         self._require_eval()
         n, c, t, v, m = x.shape
         return self.head(self.features(x), n, m)
+
+    def set_latency_mode(self, split_k: int = 4, gcn_split_k: int = None):
+        """Small-batch clip inference: split the K loops of every block over workgroups (blocks.set_clip_latency_mode)."""
+        from .blocks import set_clip_latency_mode
+        return set_clip_latency_mode(self, split_k, gcn_split_k)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 12
+#define CSK_ABI_VERSION 13
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -114,6 +114,20 @@ int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const 
                       const float *bias, float *out,
                       int n_seg, int c, int c_out, int t_in, int V, int k, int stride, int pad,
                       int res_mode, int c_res, int t_res, int res_off, int relu, void *stream);
+
+/*
+ * csk_tcn_stage_f32 for launches of a FEW tiles (small-batch clip inference; the reference's own CPU protocol is batch 1,
+ * scripts/benchmark_all_ntu60.py:17): the K loop of every output tile is cut into `ksplit` channel ranges walked by
+ * separate workgroups; raw partial sums go to `partial` ([n_seg * ksplit][c_out][t_out * V] floats, 16-byte aligned) and a
+ * second launch adds them IN SPLIT ORDER, then bias, identity residual and ReLU (the conv residual rides in split 0).
+ * Same method and arguments as csk_tcn_stage_f32 (models/base.py:302-304 + 376-387); k must be 9.  For a given ksplit the
+ * result of a clip does not depend on n_seg; against ksplit = 1 it differs by the summation order only.
+ */
+int csk_tcn_stage_splitk_f32(const float *y, const float *w, const float *x_res, const float *w_res,
+                             const float *bias, float *out,
+                             int n_seg, int c, int c_out, int t_in, int V, int k, int stride, int pad,
+                             int res_mode, int c_res, int t_res, int res_off, int relu, int ksplit, float *partial,
+                             void *stream);
 
 /*
  * Bare 1 x 1 conv + bias on the layouts of csk_gcn_stage_f32 (no adjacency, no residual, no ReLU): the six a_i / b_i

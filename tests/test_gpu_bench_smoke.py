@@ -24,7 +24,8 @@ def _run(*args):
 def test_bench_line_contract(workload):
     d = _run("--workload", workload, "--batch", "4", "--streams", "8", "--steps", "2", "--warmup", "1", "--step-cycles", "2",
              "--stream-shards", "2", "--cpu-budget", "6", "--config4-batch", "2", "--config4-streams", "6",
-             "--cpu-budget-config4", "4", "--latency-frames", "12", "--config5-batch", "6")
+             "--cpu-budget-config4", "4", "--latency-frames", "12", "--config5-batch", "6", "--clip-latency-forwards", "6",
+             "--kernel-cycles", "2")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -42,6 +43,15 @@ def test_bench_line_contract(workload):
     if workload in ("clip", "both"):          # configs[4]'s per-GPU shard (1024 clips in a real run) beside the headline, also at N = 1
         assert d["config5"]["clips_per_gpu"] == 6 and d["config5"]["global_batch"] == 6 and d["config5"]["value"] > 0
         assert "no collective" in d["config5"]["workload"] and 0 < d["config5"]["roofline_config"]["frac"] < 1
+    if workload in ("clip", "both"):          # small-batch clip latency: batch 1 and 8, eager and hipGraph, default and latency mode
+        cl = d["clip_latency"]
+        assert [r["batch"] for r in cl["per_batch"]] == [1, 8] and cl["cpu_oracle_batch1_ms"] > 0
+        for r in cl["per_batch"]:
+            for mode in ("default", "latency_mode"):
+                e = r[mode]
+                assert 0 < e["graph_ms_p50"] <= e["graph_ms_p99"] and 0 < e["eager_ms_p50"] <= e["eager_ms_p99"] and e["pipelined_ms"] > 0
+                assert e["max_abs_logit_diff_vs_default"] < 1e-4
+            assert r["default"]["split_k"] == 0 and r["latency_mode"]["split_k"] == 4 and 0 < r["roofline_config_frac_best_graph_p50"] < 1
     if workload in ("clip", "both"):          # the opt-in precision mode is reported under its own key, never as the headline
         b3 = d["clip_bf16x3"]
         assert b3["value"] > 0 and "bf16x3" in b3["dtype"] and b3["max_abs_logit_diff_vs_f32"] < 1e-4 and d["dtype"] == "f32"

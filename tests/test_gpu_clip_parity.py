@@ -219,3 +219,69 @@ def test_graph_conv_split_k_entry_vs_oracle_and_unsplit(ci, co, v, t, n, ksplit)
     native.check(rc, "csk_gcn_stage_splitk_f32")
     check_parity(y.cpu(), want, shape=(ci, co, v, t, n, ksplit))
     check_parity(y.cpu(), plain.cpu(), note="split-K vs unsplit graph conv (summation order)")
+
+
+@pytest.mark.parametrize("ci,co,stride,res,T,N,ksplit", [
+    (64, 64, 1, True, 37, 2, 4),       # identity residual, 64-row tiles, ragged last tile
+    (64, 128, 2, True, 50, 2, 8),      # strided conv residual (rides in split 0), 128-row tiles
+    (128, 256, 2, True, 31, 1, 5),     # a factor that does not divide the 16 chunks evenly
+    (256, 256, 1, True, 12, 2, 32),    # as many ranges as 8-channel chunks
+    (64, 64, 1, False, 20, 1, 3),      # no residual
+    (40, 72, 1, True, 11, 2, 6),       # ragged channel counts: more ranges asked for than the 5 chunks allow
+])
+def test_temporal_conv_split_k_entry_vs_oracle_and_unsplit(ci, co, stride, res, T, N, ksplit):
+    """csk_tcn_stage_splitk_f32 (clip latency mode: the K loop of the 9 x 1 temporal conv cut into channel ranges over
+    workgroups + tcn_reduce_kernel): the block's output within 1e-4 of the oracle and of the unsplit launch (summation
+    order only), for every residual form; unwritten partial sums would show up as NaN."""
+    torch.manual_seed(77 + ci + co + T)
+    m = pkg.SpatioTemporalBlock(ci, co, _A(), stride, res).eval()
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("graph_attn") or name.endswith("bn.weight") or name.endswith("residual.1.weight"):
+                prm.copy_(torch.rand_like(prm) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_(torch.rand_like(prm) - 0.5)
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand_like(buf) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.rand_like(buf) - 0.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.rand(N, ci, T, 25)
+    want = unit_scale_(m, sd, lambda s: o.st_block(x, s, "", stride, res), BLOCK_OUT_KEYS)
+    m = m.to(DEV)
+    plain = m(x.to(DEV)).cpu()
+    from continual_skeletons_amd import blocks
+    blocks.split_scratch(torch.device(DEV), 1 << 22).fill_(float("nan"))
+    m.clip_split_k = ksplit                                   # the temporal conv only (the graph conv has its own test)
+    got = m(x.to(DEV)).cpu()
+    check_parity(got, want, shape=(ci, co, stride, res, T, N, ksplit))
+    check_parity(got, plain, note="split-K vs unsplit temporal conv (summation order)")
+
+
+def test_clip_latency_mode_full_model_golden_and_batch_invariance():
+    """StGcn.set_latency_mode (split-K on every block's graph conv and temporal conv): G6 logits and layer taps within
+    1e-4; a clip's logits are BITWISE the same alone and in a batch (the split factor never depends on the batch); the
+    default mode comes back with split_k = 0."""
+    a, sd, x = g6_state_dict("ntu")
+    net = pkg.StGcn(_A()).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    base = net(x.to(DEV)).cpu()
+    net.set_latency_mode(4)
+    assert all(net.layers[f"layer{i}"].clip_split_k == 4 for i in range(1, 11)) and net.layers.layer2.gcn.clip_split_k == 4
+    taps = {}
+    hooks = [net.layers[f"layer{i}"].register_forward_hook(lambda m, inp, out, i=i: taps.__setitem__(i, out)) for i in (1, 5, 8, 10)]
+    both = net(x.to(DEV)).cpu()
+    for h in hooks:
+        h.remove()
+    for i in (1, 5, 8, 10):
+        check_parity(taps[i].cpu().reshape(-1)[::997], a[f"layer{i}_sub"], note=f"latency mode layer{i}")
+    check_parity(both, a["logits"], note="latency mode logits")
+    check_parity(both, base, note="latency mode vs default (summation order)")
+    one = net(x[:1].to(DEV)).cpu()
+    assert torch.equal(one, both[:1])                         # batch-invariant for a fixed split_k
+    net.set_latency_mode(0)
+    assert torch.equal(net(x.to(DEV)).cpu(), base)
+    with pytest.raises(ValueError):
+        pkg.set_clip_latency_mode(torch.nn.Linear(2, 2))

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cskel.h but not exported"
     assert declared - {"csk_last_error"} == set(pkg.native.SIGNATURES), "ctypes table out of sync with cskel.h"
-    assert pkg.native.lib().csk_abi_version() == pkg.native.ABI_VERSION == 12
+    assert pkg.native.lib().csk_abi_version() == pkg.native.ABI_VERSION == 13
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -505,3 +505,56 @@ def test_roofline_config_prices_n_ranks_against_n_peaks():
     # the online leg: 1024 streams, 4-frame cycle at the round-4 rate (4.12 ms per cycle) -> 0.70 at any N
     sa, se, sb = workmodel.step_totals(2048, 4)
     assert abs(workmodel.roofline_config(8 * sa, 8 * sb, 4.12e-3, 8 * se, n_gpus=8)["frac"] - workmodel.roofline_config(sa, sb, 4.12e-3, se)["frac"]) < 1e-9
+
+
+def test_round5_split_k_tcn_entry_validates_its_arguments_without_a_gpu():
+    """csk_tcn_stage_splitk_f32: argument errors are reported before anything is launched."""
+    import ctypes as C
+    lib = pkg.native.lib()
+    fake = C.c_void_p(0x1000)
+
+    def tcn(ksplit=4, partial=fake, k=9, c=64, res=1, c_res=64):
+        return lib.csk_tcn_stage_splitk_f32(fake, fake, fake, None, fake, fake, 1, c, 64, 20, 25, k, 1, 4 if k == 9 else 0, res, c_res, 20, 0, 1,
+                                            ksplit, partial, None)
+    assert tcn(ksplit=0) == -1 and b"ksplit must be in [1, 64]" in lib.csk_last_error()
+    assert tcn(ksplit=65) == -1 and b"ksplit must be in [1, 64]" in lib.csk_last_error()
+    assert tcn(partial=None) == -1 and b"partial-sum buffer" in lib.csk_last_error()
+    assert tcn(partial=C.c_void_p(0x1004)) == -1 and b"16-byte aligned" in lib.csk_last_error()
+    assert tcn(k=1) == -1 and b"9-tap" in lib.csk_last_error()
+    assert tcn(c_res=32) == -1 and b"identity residual" in lib.csk_last_error()
+
+
+def test_folded_operand_cache_sees_every_kind_of_weight_edit():
+    """_Folded._packed_ops re-reads a snapshot of dict slots instead of walking parameters() on every call; every way the
+    weights can change must still refold on the NEXT call: in-place edit, p.data = ..., replaced Parameter, swapped
+    sub-module, load_state_dict -- and an untouched module must NOT refold."""
+    A = pkg.ntu_graph().A
+    blk = pkg.SpatioTemporalBlock(4, 8, A, stride=2).eval()
+    ops0 = blk._packed_ops("cpu")
+    assert blk._packed_ops("cpu") is ops0                                   # cached
+    g0 = blk.gcn._packed_ops("cpu")
+    with torch.no_grad():
+        blk.tcn.bn.weight.mul_(2.0)                                         # in-place: version counter
+    ops1 = blk._packed_ops("cpu")
+    assert ops1 is not ops0 and not torch.equal(ops1["w"], ops0["w"])
+    assert blk.gcn._packed_ops("cpu") is g0                                 # the graph conv's cache watches its own tensors only
+    blk.tcn.t_conv.bias.data = torch.ones_like(blk.tcn.t_conv.bias)         # p.data = ...: storage pointer
+    ops2 = blk._packed_ops("cpu")
+    assert ops2 is not ops1 and not torch.equal(ops2["bias"], ops1["bias"])
+    blk.residual.t_conv.weight = torch.nn.Parameter(torch.zeros_like(blk.residual.t_conv.weight))    # replaced Parameter
+    ops3 = blk._packed_ops("cpu")
+    assert ops3 is not ops2 and float(ops3["w_res"].abs().max()) == 0.0
+    blk.tcn.bn = torch.nn.BatchNorm2d(8).eval()                             # swapped sub-module
+    ops4 = blk._packed_ops("cpu")
+    assert ops4 is not ops3
+    blk.load_state_dict({k: v.clone() + 0.25 for k, v in blk.state_dict().items()})
+    assert blk._packed_ops("cpu") is not ops4
+    assert blk.gcn._packed_ops("cpu") is not g0                             # load_state_dict copied into the graph conv's tensors too
+    net = pkg.StGcn(A, input_shape=(3, 20, 25, 2)).eval()
+    n0 = net._packed_ops("cpu")
+    with torch.no_grad():
+        net.fc.weight.add_(1.0)                                             # not one of the driver's folded tensors
+    assert net._packed_ops("cpu") is n0
+    with torch.no_grad():
+        net.data_bn.running_mean.add_(1.0)
+    assert net._packed_ops("cpu") is not n0
