@@ -264,38 +264,28 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
     THROUGHPUT_SPLIT_K = 3   # split-K of the 256-channel blocks (see _pick_ksplit)
 
     def _pick_ksplit(self, p: int) -> int:
-        """Split-K factor of this block's TCN step (csk_tcn_step_f32 ``ksplit``).
+        """Split-K factor of this block's TCN step (csk_tcn_step_f32 ``ksplit``) -- a function of (C_out, split_k) ONLY: a
+        stream's results never depend on how many streams share the slab (``p`` is not used).
         * Blocks with C_out >= 256 always cut their 2304-deep K loop into 3 channel ranges: their tiles are the longest
           of the stack (128 x 128 x 2304) and come 400-800 per launch for 512 resident slots; three times as many tiles a
           third as long pack the GPU better (measured at 1024 streams, two shards, 4 frames per launch: 954 k -> 966 k /
-          980 k / 965 k frames/s for 2 / 3 / 4 splits; splitting the 128-channel blocks as well: 944 k).  The factor does
-          NOT depend on the slab size, so a stream's results do not depend on how many streams share the slab.
-        * Latency mode (``split_k`` > 1, a handful of streams): up to ``split_k`` ranges when the launch would otherwise
-          hold fewer than 64 workgroups, at least two 8-channel chunks per split."""
+          980 k / 965 k frames/s for 2 / 3 / 4 splits; splitting the 128-channel blocks as well: 944 k).
+        * Latency mode (``split_k`` > 1, meant for a handful of streams): up to 4 * split_k ranges (<= 32), at least one
+          8-channel chunk each -- a 9-tap chunk is 3.8 us of MFMAs for one workgroup, and with a handful of tiles the other
+          250 CUs are idle anyway.  (Until round 4 the factor was also capped by 256 // tiles, i.e. by the slab size: one
+          stream got 32 ranges at C = 256 and sixteen streams 18 -- different summation orders for the same stream.)"""
         base = self.THROUGHPUT_SPLIT_K if self.out_channels >= 256 else 1
         if self.split_k <= 1:
             return base
-        mt = 128 if self.out_channels % 128 == 0 else 64
-        tiles = -(-p // (16384 // mt)) * (-(-self.out_channels // mt))
-        if tiles >= 64:
-            return base
-        # up to 4 * split_k ranges (<= 32) while a split keeps at least one 8-channel chunk and the launch stays below
-        # ~256 workgroups: a 9-tap chunk is 3.8 us of MFMAs for one workgroup, and with a handful of tiles the other
-        # 250 CUs are idle anyway
-        want = min(4 * self.split_k, 32, -(-self.out_channels // 8), max(1, 256 // tiles))
-        return max(base, want)
+        return max(base, min(4 * self.split_k, 32, -(-self.out_channels // 8)))
 
     def _pick_gcn_ksplit(self, p: int) -> int:
         """Split-K factor of this block's graph conv (csk_gcn_stage_splitk_f32), latency mode only: with a handful of
         streams one workgroup per tile walks all 3 * C_in / 8 K-chunks alone (52 us at C_in = 256 -- 60 % of a frame's
-        latency at one stream, profiles/r04_latency_1stream.md); a function of (C_in, split_k) only."""
+        latency at one stream, profiles/r04_latency_1stream.md).  A function of (C_in, split_k) only (``p`` is not used)."""
         if self.split_k <= 1 or type(self.gcn) is not GraphConvolution or self.in_channels < 16:
             return 1
-        mt = 128 if self.out_channels % 128 == 0 else 64
-        tiles = -(-p // (16384 // mt)) * (-(-self.out_channels // mt))
-        if tiles >= 64:
-            return 1
-        return max(1, min(4 * self.split_k, 32, -(-self.in_channels // 8), max(1, 256 // tiles)))
+        return max(1, min(4 * self.split_k, 32, -(-self.in_channels // 8)))
 
     def clean_state(self):
         if self._state is not None:
@@ -344,7 +334,7 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
         slot0 = st.e % OUT
         # one launch; with split-K at most max_emit emissions per launch (the scratch holds that many partial sums) --
         # only the end-padding flush of a stack exceeds it (per-output summation order does not depend on the grouping)
-        group = n_emit if st.partial is None else min(n_emit, st.max_emit)
+        group = n_emit if (st.partial is None or st.ksplit <= 1) else min(n_emit, st.max_emit)     # only a split temporal conv is bound by the scratch
         for e0 in range(0, n_emit, group):
             ne, f0 = min(group, n_emit - e0), first + e0 * self.stride
             blocks.tcn_step_launch(

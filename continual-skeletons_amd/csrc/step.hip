@@ -12,6 +12,8 @@
 // positions, so the GEMM is  D[co, p] = sum_r sum_c W[r][c][co] * ring[(head - 8 + r) % slots][c][p].
 // Zero-initialised slots reproduce the zero left-padding of the clip conv (models/base.py:307-334 semantics).
 // (A bare CoTemporalConvolution uses the same kernel on a ring of exactly k slots.)
+#include <type_traits>
+
 #include "mfma_core.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -96,7 +98,7 @@ struct StepParams {
 // E = emissions per workgroup tile (folded into the tile's column axis, see RingStage), HS = head_step of the launch
 // (1, or 2 for a stride-2 block; only meaningful for E > 1).  SPLIT = false is the throughput kernel; the split-K form
 // is a separate instantiation (E = 1) so that its extra index arithmetic costs the default path nothing.
-template <int MT, int E, int HS, bool SPLIT, bool K9 = true>
+template <int MT, int E, int HS, bool SPLIT, bool K9 = true, bool HALVES = false>
 __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx, const int by, const int bz, float *smem) {
     constexpr int NT = 16384 / MT;
     constexpr int NP = NT / E;                      // positions per tile
@@ -148,9 +150,14 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
     {
         const float *wbase = p.w + m0 + (size_t)cb * p.Mpad;
         const float *rbase = p.ring + (int64_t)cb * P + p0;
-        ws.setup(p.K, p.Cpad, p.Mpad, tid);
+        // 9-tap chunks: the compact weight staging of mfma_core.h (one offset register instead of 2 x WB)
+        using WS9 = typename std::conditional<MT == 128, WStage9x128, WStage9x64>::type;
+        typename std::conditional<K9, WS9, WStage<MT> &>::type ws1 = [&]() -> decltype(auto) {
+            if constexpr (K9) { WS9 w9; w9.setup(p.Cpad, p.Mpad, tid); return w9; }
+            else { ws.setup(p.K, p.Cpad, p.Mpad, tid); return (ws); }
+        }();
         rs.setup(p0, P, tid);
-        ws.issue(wbase);
+        ws1.issue(wbase);
         rs.window(first, 1, p.slots, nwin, p.C, P);
         rs.issue(rbase, Cl, P, 0);
         const int t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
@@ -158,27 +165,27 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
         int c0 = 0;
         for (; c0 + KC < CpadL; c0 += KC) {
             __syncthreads();
-            ws.commit(Wl);
+            ws1.commit(Wl);
             rs.commit(Bl);
             __syncthreads();
             // next chunk's loads in three bursts between three tap segments (see mfma_taps in mfma_core.h)
             const float *wnext = wbase + (size_t)(c0 + KC) * p.Mpad;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) ws.issue_slot(j, wnext);
+            for (int j = 0; j < 3; ++j) ws1.issue_slot(j, wnext);
             rs.template issue_third<0>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
             if (k9) mfma_taps_ct<MT, 3>(Wl, Bl, 0, NP, KC * NP, offA, off0, off1, kh, acc);
             else mfma_taps<MT>(Wl, Bl, 0, t1, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-            for (int j = 3; j < 6; ++j) ws.issue_slot(j, wnext);
+            for (int j = 3; j < 6; ++j) ws1.issue_slot(j, wnext);
             rs.template issue_third<1>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
             if (k9) mfma_taps_ct<MT, 3>(Wl, Bl, 3, NP, KC * NP, offA, off0, off1, kh, acc);
             else if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, NP, KC * NP, offA, off0, off1, kh, acc);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-            for (int j = 6; j < 9; ++j) ws.issue_slot(j, wnext);
+            for (int j = 6; j < 9; ++j) ws1.issue_slot(j, wnext);
             rs.template issue_third<2>(rbase, Cl, P, c0 + KC);
             __builtin_amdgcn_s_setprio(1);
             if (k9) mfma_taps_ct<MT, 3>(Wl, Bl, 6, NP, KC * NP, offA, off0, off1, kh, acc);
@@ -186,7 +193,7 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
-        ws.commit(Wl);
+        ws1.commit(Wl);
         rs.commit(Bl);
         __syncthreads();
         mfma_chunk<MT>(Wl, Bl, p.K, NP, KC * NP, offA, off0, off1, kh, acc);
@@ -224,43 +231,40 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
     const bool full = p.fast_epi && m0 + MT <= p.Cout;
     const unsigned kh4 = 4u * (unsigned)kh;
     const int pw = p0 + cw;                                   // first position of this wave's columns
+    // Operands are loaded and consumed one 32-row half (mi) at a time when HALVES (the 168-register instantiation: 64
+    // accumulators + 2 x 48 operands would not fit), else both halves up front (all loads in flight together).
     float bv[2][16], rv[2][2][16];
-    if (full) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+    auto load_half = [&](int mi) {
+        if (full) {
 #pragma unroll
             for (int g = 0; g < 16; ++g)
                 bv[mi][g] = split ? 0.f : ld_lane(p.bias + (rbase + mi * 32 + (g & 3) + 8 * (g >> 2)), kh4 * 4u);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const unsigned lo = 4u * (kh4 * (unsigned)P + (unsigned)min((int64_t)(pw + ni * 32 + l31), P - 1));
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 2; ++ni) {
+                const unsigned lo = 4u * (kh4 * (unsigned)P + (unsigned)min((int64_t)(pw + ni * 32 + l31), P - 1));
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const float *rrow = xres + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * P;
                     rv[ni][mi][g] = ident ? ld_lane(rrow, lo) : 0.f;
                 }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            }
+        } else {
 #pragma unroll
             for (int g = 0; g < 16; ++g) bv[mi][g] = split ? 0.f : p.bias[rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2)];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int64_t qc = min((int64_t)(pw + ni * 32 + l31), P - 1);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 2; ++ni) {
+                const int64_t qc = min((int64_t)(pw + ni * 32 + l31), P - 1);
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int co = rbase + mi * 32 + 4 * kh + (g & 3) + 8 * (g >> 2);
                     rv[ni][mi][g] = ident ? xres[(int64_t)min(co, p.Cout - 1) * P + qc] : 0.f;
                 }
+            }
         }
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    };
+    const int64_t qb = (int64_t)pw + lane;
+    const bool qv = qb < P;
+    auto finish_half = [&](int mi) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             float v0 = acc[mi][0][g] + bv[mi][g] + rv[0][mi][g];
@@ -270,41 +274,50 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
             acc[mi][0][g] = __uint_as_float(sw[0]);            // row rbase + mi*32 + (g&3) + 8(g>>2), column qb
             acc[mi][1][g] = __uint_as_float(sw[1]);            // row + 4
         }
-    const int64_t qb = (int64_t)pw + lane;
-    const bool qv = qb < P;
-    if (full) {
-        if (qv) {
-            const unsigned qo = 4u * (unsigned)qb;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+        if (full) {
+            if (qv) {
+                const unsigned qo = 4u * (unsigned)qb;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     float *orow = out + (int64_t)(rbase + mi * 32 + (g & 3) + 8 * (g >> 2)) * P;
                     st_lane(orow, qo, acc[mi][0][g]);
                     st_lane(orow + 4 * P, qo, acc[mi][1][g]);
                 }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            }
+        } else {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int row0 = rbase + mi * 32 + (g & 3) + 8 * (g >> 2);
                 if (qv && row0 < p.Cout) out[(int64_t)row0 * P + qb] = acc[mi][0][g];
                 if (qv && row0 + 4 < p.Cout) out[(int64_t)(row0 + 4) * P + qb] = acc[mi][1][g];
             }
+        }
+    };
+    if (HALVES) {
+        load_half(0);
+        finish_half(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_half(1);
+        finish_half(1);
+    } else {
+        load_half(0);
+        load_half(1);
+        finish_half(0);
+        finish_half(1);
     }
 }
 
-template <int MT, int E, int HS, bool SPLIT, bool K9>
-__global__ __launch_bounds__(NTHREADS, 2) void tcn_step_kernel(const StepParams p) {
+// OCC = 3: the same kernel within 168 registers (three workgroups per CU), for launches whose workgroup count fits 768 resident
+// slots in fewer rounds than 512 (CoAGCN at the Kinetics shape: 576 tiles per 64-channel block)
+template <int MT, int E, int HS, bool SPLIT, bool K9, int OCC = 2>
+__global__ __launch_bounds__(NTHREADS, OCC) void tcn_step_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware work-item order (mfma_core.h): every XCD walks a contiguous range of items; m-tile fastest, then emission
     // group, then position tile -- the m-tiles of a position tile read the SAME ring window (and emission groups at the
     // same positions all but a few slots of it); with a plain (x, y, z) grid they sat gridDim.x dispatches apart, by when
     // the window had left the 4 MB L2 (C = 256 launches fetched 966 MB for 525 MB of operands)
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    tcn_step_tile<MT, E, HS, SPLIT, K9>(p, (int)(wid / (p.gy * p.gz)), (int)(wid % p.gy), (int)((wid / p.gy) % p.gz), smem);
+    tcn_step_tile<MT, E, HS, SPLIT, K9, OCC == 3>(p, (int)(wid / (p.gy * p.gz)), (int)(wid % p.gy), (int)((wid / p.gy) % p.gz), smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,6 +662,13 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     p.gx = (unsigned)((P + NP - 1) / NP); p.gy = (unsigned)(p.Mpad / MT); p.gz = (unsigned)((n_emit / E) * p.ksplit);
     if ((int64_t)p.gx * p.gy * p.gz >= (1ll << 31)) CSK_FAIL("tcn_step: grid too large");
     dim3 grid(p.gx * p.gy * p.gz);
+    // The 64-row, four-emission form also exists within 168 registers (three workgroups per CU, 43 KB of LDS each): taken when
+    // the launch needs fewer rounds of 768 resident workgroups than of 512 (256 CUs) -- CoAGCN at the Kinetics shape is 576
+    // tiles per 64-channel block: one round instead of a full one plus an eighth.  A function of the launch size only.
+    if (!big && E == 4 && p.ksplit == 1 && k9 && !csk_diag_flag("CSK_STEP_NOOCC3")) {
+        const unsigned g = grid.x;
+        if ((g + 767) / 768 < (g + 511) / 512) kern = tcn_step_kernel<64, 4, 1, false, true, 3>;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, p);

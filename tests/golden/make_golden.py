@@ -249,7 +249,11 @@ def generate():
     #       a_conv / b_conv (the per-sample attention), logits + layer 1/5/8/10 taps
     out["g8_agcn_kin"] = _whole_model(R, R.AGcn, R.A_kin, G8["V"], G8["classes"], G8["n"], G8["seed"], G8["gcn_bn_scale"])
     # G9 -- CoModelBase.map_state_dict (models/base.py:200-224), the reference's regular -> continual key map: pure
-    #       string code, executed UNBOUND on a stub nn.Module whose state_dict keys are the continual key layout
+    #       string code, executed UNBOUND on a stub nn.Module whose state_dict keys are the continual key layout.
+    #       What is EXECUTED is the mapping function; the continual key LAYOUT (co_keys) is DERIVED by _co_key below from
+    #       the container structure of base.py:412-446 as the reference's tests spell it out -- continual-inference is not
+    #       installable here, so it is not the state_dict() of a real CoStGcn (buffers co.Delay / co.Conv2d may register
+    #       are not covered).  Regenerate co_keys from the real class if the library ever becomes available.
     out["g9_key_map"] = _key_map(R)
     # G10 -- aggregate_preds (scripts/multi_stream_eval.py:33-42), the reference's own multi-stream logit fusion, executed
     #        under the same name-only stubs: np.add / np.maximum over 1-4 streams, 2-D (N, classes) and 3-D (N, classes,

@@ -58,6 +58,32 @@ def test_adaptive_graph_conv_vs_oracle(ci, co, t, v):
     check_parity(got, want, shape=(ci, co, t, v))
 
 
+@pytest.mark.parametrize("ci,co,t,v,scale", [(64, 64, 12, 18, 6.0), (64, 64, 1, 18, 6.0), (128, 128, 1, 18, 4.0), (64, 128, 9, 25, 6.0),
+                                             (64, 64, 1, 25, 8.0)])
+def test_adaptive_graph_conv_peaked_attention(ci, co, t, v, scale):
+    """The softmax of every attention kernel uses v_exp_f32 after a multiply by log2(e) and one reciprocal per column:
+    its relative error grows with |logit|.  Large embedding weights make the logits span tens of units (PEAKED attention with
+    large negative arguments, which the near-uniform random fixtures never exercise): clip form (T > 1, softmax launch /
+    fused partial logits) and step form (T = 1, the per-frame fused kernel) must stay within 1e-4 of the oracle's exact exp."""
+    A = A_KIN if v == 18 else pkg.ntu_graph().A
+    m = pkg.AdaptiveGraphConvolution(ci, co, A).eval()
+    _randomise(m, 90 + ci + t)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if ("a_conv" in name or "b_conv" in name) and name.endswith("weight"):
+                prm.mul_(scale)
+    sd = {k: v_.clone() for k, v_ in m.state_dict().items()}
+    x = torch.rand(2, ci, t, v, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():                                    # the logits the softmax sees (models/a_gcn/a_gcn.py:53-62)
+        a1 = torch.nn.functional.conv2d(x, sd["a_conv.0.weight"], sd["a_conv.0.bias"]).permute(0, 3, 1, 2).reshape(2, v, -1)
+        a2 = torch.nn.functional.conv2d(x, sd["b_conv.0.weight"], sd["b_conv.0.bias"]).reshape(2, -1, v)
+        logits = torch.matmul(a1, a2) / a1.shape[-1]
+    assert float(logits.max() - logits.min()) > 20.0, float(logits.max() - logits.min())     # tens of units: a peaked softmax
+    want = unit_scale_(m, sd, lambda s: o.adaptive_graph_conv(x, s), GCN_OUT_KEYS)
+    got = m.to(DEV)(x.to(DEV)).cpu()
+    check_parity(got, want, shape=(ci, co, t, v, scale), note="peaked attention (v_exp_f32 softmax)")
+
+
 @pytest.mark.parametrize("v,t", [(25, 23), (18, 30)])
 def test_fused_attention_entry_clip_form_equals_two_launch_route(v, t):
     """csk_agcn_embed_attention_f32, per-segment form, called directly (the module uses it at V = 18 only: at V = 25 it measured

@@ -51,7 +51,9 @@ def main(tag, out_tag):
     L = [f"# PMC passes ({out_tag}): tools/profile_r04.sh -- `rocprofv3 --kernel-trace --pmc ...` of tools/clip_pass.py (batch 256, both precision "
          "modes), tools/agcn_prof.py (A-GCN, Kinetics shape, batch 64) and tools/online_pass.py --shards 1 (the online shapes: CoST-GCN and "
          "CoAGCN, 1024 streams, 4-frame cycles); separate passes for SQ counters, FETCH_SIZE and WRITE_SIZE", ""]
-    for mode, title in (("f32", "ST-GCN clip forward, exact fp32"), ("bf16x3", "ST-GCN clip forward, opt-in bf16x3 temporal conv"),
+    stage_entries = []
+    for mode, title in (("f32", "ST-GCN clip forward, exact fp32"), ("f32_b1024", "ST-GCN clip forward, exact fp32, batch 1024 (one rank's shard of configs[4])"),
+                        ("bf16x3", "ST-GCN clip forward, opt-in bf16x3 temporal conv"),
                         ("agcn", "A-GCN clip forward (config 4)"),
                         ("online_costgcn", "online: CoST-GCN, 1024 streams, one stream shard, 4 frames per launch (configs[2] launch shapes)"),
                         ("online_coagcn", "online: CoAGCN, Kinetics shape, 1024 streams, one stream shard, 4 frames per launch (configs[3])")):
@@ -60,10 +62,11 @@ def main(tag, out_tag):
         write, _ = pmc(d, f"write_{mode}")
         if not sq:
             continue
-        known = 256 * 3 * 300 * 25 * 2 * 4
+        batch = 1024 if mode.endswith("b1024") else 256
+        known = batch * 3 * 300 * 25 * 2 * 4
         cal_raw = fetch.get("input_norm_kernel", {}).get("FETCH_SIZE", [])
-        cal = known / (max(cal_raw) * 1024) if cal_raw and mode in ("f32", "bf16x3") else 2.0
-        L += [f"## {title}", "", f"(FETCH_SIZE calibration on input_norm_kernel, {known / 1e6:.2f} MB known: factor {cal:.3f})" if mode in ("f32", "bf16x3") else
+        cal = known / (max(cal_raw) * 1024) if cal_raw and mode in ("f32", "bf16x3", "f32_b1024") else 2.0
+        L += [f"## {title}", "", f"(FETCH_SIZE calibration on input_norm_kernel, {known / 1e6:.2f} MB known: factor {cal:.3f})" if mode in ("f32", "bf16x3", "f32_b1024") else
               "(FETCH_SIZE x 2: the gfx950 correction of MI355X_MICROARCH.md, as calibrated in the ST-GCN passes)", "",
               "| kernel | launches | avg ms | clock GHz | MFMA busy | waves/SIMD | WAIT_ANY/wave | WAIT_INST/wave | HBM read MB | HBM write MB |",
               "|---|---|---|---|---|---|---|---|---|---|"]
@@ -95,13 +98,16 @@ def main(tag, out_tag):
                            "streams": 1024, "stream_shards": 1, "frames_per_launch": 4,
                            "note": "average over the tcn_step_kernel launches of blocks 5-10 (split-K launches include their step_reduce_kernel)"},
                           open(os.path.join(ROOT, "profiles", "traffic_tcn_step.json"), "w"), indent=1)
-        if mode == "f32":
+        if mode in ("f32", "f32_b1024"):
             dom = [v for k, v in traffic.items() if k.startswith("tcn_stage_kernel")]
             if dom and all(v["read_MB"] == v["read_MB"] for v in dom):
                 n = sum(v["launches"] for v in dom)
                 hb = sum((v["read_MB"] + v["write_MB"]) * 1e6 * v["launches"] for v in dom) / n
-                json.dump({"kernel": "tcn_stage_kernel", "hbm_bytes_per_launch": hb, "launches": n, "source": f"profiles/{out_tag}_pmc_summary.md",
-                           "batch": 256}, open(os.path.join(ROOT, "profiles", "traffic_tcn_stage.json"), "w"), indent=1)
+                stage_entries.append({"kernel": "tcn_stage_kernel", "hbm_bytes_per_launch": hb, "launches": n,
+                                      "source": f"profiles/{out_tag}_pmc_summary.md", "batch": batch})
+                # one entry per profiled batch size (bench.py: load_traffic(batch=...)); the batch-256 entry stays at the top level too
+                top = next((e for e in stage_entries if e["batch"] == 256), stage_entries[0])
+                json.dump(dict(top, by_batch=stage_entries), open(os.path.join(ROOT, "profiles", "traffic_tcn_stage.json"), "w"), indent=1)
     open(os.path.join(ROOT, "profiles", f"{out_tag}_pmc_summary.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L))
 
