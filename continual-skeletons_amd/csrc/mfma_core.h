@@ -174,9 +174,9 @@ struct WStage9x64 {
 // activations: KC channel rows x span positions of one segment -> Bl [KC][ldb]; positions outside [0, TV)
 // and channels >= C read as zero (conv zero padding / channel padding): the address is clamped into the
 // tensor and the value replaced by 0 with a select, so the load itself is unconditional.
-template <int NJ>
+template <int NJ, int RPW_ = KC / (NTHREADS / 64)>
 struct BStage {
-    static constexpr int RPW = KC / (NTHREADS / 64);   // rows per wave
+    static constexpr int RPW = RPW_;                   // rows per wave (2 for an 8-channel chunk; 2 G for G channel groups)
     // slot u of a lane is position j = min(u * 64 + lane, span - 1) of the LDS row = position clamp(pbase + j) of the channel
     // row; both are recomputed where they are used (two or three integer operations per access, boundary tiles only) instead
     // of 2 NJ registers held across the K loop -- the 9-tap kernels run at the 256-register limit
@@ -195,7 +195,12 @@ struct BStage {
             valid |= (pp >= 0 && pp < TV) ? (1u << u) : 0u;
         }
     }
-    __device__ __forceinline__ unsigned goff(int u) const { return (unsigned)min(max(pbase_ + min(u * 64 + lane_, spanm1), 0), tvm1); }
+    // (the empty asm keeps the compiler from hoisting the NJ offsets out of the K loop into registers again)
+    __device__ __forceinline__ unsigned goff(int u) const {
+        int l = lane_;
+        asm volatile("" : "+v"(l));
+        return (unsigned)min(max(pbase_ + min(u * 64 + l, spanm1), 0), tvm1);
+    }
     // slot u of every row this wave owns (used to trickle the loads between MFMA groups)
     __device__ __forceinline__ void issue_slot(int u, const float *__restrict__ seg_base, int C, int64_t chan_stride,
                                                int c0, int wave) {
@@ -230,7 +235,11 @@ struct BStage {
         for (int rr = 0; rr < RPW; ++rr) {
             float *dst = Bl + (wave + rr * (NTHREADS / 64)) * ldb;
 #pragma unroll
-            for (int u = 0; u < NJ; ++u) dst[min(u * 64 + lane_, spanm1)] = v[rr][u];
+            for (int u = 0; u < NJ; ++u) {
+                int l = lane_;
+                asm volatile("" : "+v"(l));
+                dst[min(u * 64 + l, spanm1)] = v[rr][u];
+            }
         }
     }
 };

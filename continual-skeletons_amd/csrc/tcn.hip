@@ -32,13 +32,17 @@ struct TcnParams {
     int fast_epi;                 // row strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
     int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
     int vec_stage;                // 16-byte activation staging on interior tiles (diagnostic CSK_TCN_NOVEC=1 turns it off)
+    int no_peel_ct;
+    int ldb2;                     // conv-residual phase: LDS row stride of its activation tile
     int ksplit, cper;             // split-K form (csk_tcn_stage_splitk_f32): ksplit channel ranges of cper channels per tile,
     float *part;                  // raw partial sums part[(seg * ksplit + ks)][Cout][Tout * V]; ksplit == 1: off
     unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
 };
 
-template <int MT, int NJ, bool K9 = false, bool SPLIT = false>
+// VT: joints per frame as a compile-time constant (25 / 18: the tap shift of an LDS read becomes an immediate offset), 0 = run time
+template <int MT, int NJ, bool K9 = false, bool SPLIT = false, int VT = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams p) {
+    constexpr int RES_G = VT ? 4 : 2;   // 8-channel groups per chunk of the conv-residual phase
     constexpr int OCC = 2;   // 3 (epilogue operands loaded after the K loop, <= 168 registers) was measured: the K loop's
                              // staging registers then spill and the stage runs 13-19 % slower
     constexpr int NT = 16384 / MT;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
     const int cb = SPLIT ? ks * p.cper : 0;
     const int Cl = SPLIT ? min(p.C - cb, p.cper) : p.C;               // real channels of the range (>= 1 by construction)
     const int CpadL = SPLIT ? min(p.Cpad - cb, p.cper) : p.Cpad;
-    const int V = p.V, Q = p.Tout * V;
+    const int V = VT ? VT : p.V, Q = p.Tout * V;
     const int qend = min(q0 + p.nt, Q);          // p.nt == NT unless the staged span had to be narrowed (large stride * V)
     const int ta = div_magic(q0, p.vmagic), tb = div_magic(qend - 1, p.vmagic);
 
@@ -214,35 +218,70 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
             phase1(bs);
         }
         if (!conv_res && OCC == 2) { load_half(0); load_half(1); }
-        mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+        if (K9 && NJ < 9 && !p.no_peel_ct) {   // the peeled last chunk in straight-line 3-tap segments too, where the register budget allows
+                                               // (+0.1 ... +0.7 %; diagnostic CSK_TCN_NOPEELCT keeps it rolled)
+            mfma_taps_ct<MT, 3>(Wl, Bl, 0, p.ldb, V, offA, off[0], off[1], kh, acc);
+            mfma_taps_ct<MT, 3>(Wl, Bl, 3, p.ldb, V, offA, off[0], off[1], kh, acc);
+            mfma_taps_ct<MT, 3>(Wl, Bl, 6, p.ldb, V, offA, off[0], off[1], kh, acc);
+        } else {
+            mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
+        }
     }
-    // ---- phase 2: 1x1 strided residual conv over the block input (models/base.py:372-374)
+    // ---- phase 2: 1x1 strided residual conv over the block input (models/base.py:372-374).  A chunk holds G = 4 (or 2)
+    // consecutive 8-channel groups laid out like the taps of a 9-tap chunk -- Wl [G][KC][MT], Bl [G * KC][ldb2], "tap" stride
+    // KC * ldb2 -- so that the chunk's fixed cost (27 staging slots, two barriers) buys 16 G MFMAs per wave instead of 16: with
+    // one group per chunk this phase took 14 % of a stride-2 tile for 1 / 9 of its MFMAs.  Channel pairs are accumulated in
+    // the same order as before (bitwise the same sums).
     if (conv_res) {
         const int fa = p.stride * ta + p.res_off;
         const int span = (p.stride * (tb - ta) + 1) * V;
         const float *seg_base = p.xres + (int64_t)seg * p.Cres * p.Tres * V;
         const int64_t cs = (int64_t)p.Tres * V;
         const float *wbase = p.wres + m0;
-        ws.setup(1, p.CresPad, p.Mpad, tid);
-        bs.setup(fa * V, span, p.Tres * V, lane);
-        ws.issue(wbase);
-        bs.issue(seg_base, p.Cres, cs, 0, wave);
-        int c0 = 0;
-        for (; c0 + KC < p.CresPad; c0 += KC) {
+        constexpr int NJ2 = VT ? (NJ * 64 - 8 * VT + 63) / 64 : NJ;        // span2 = span1 - 8 V <= 64 NJ - 8 V
+        {
+            // 4 groups per chunk in the instantiations with a compile-time joint count (their residual tile is NJ2 <= 6 sweeps
+            // wide: 8 rows x 6 sweeps of staging registers); the others stage 2 groups -- the host sizes the LDS for it
+            constexpr int G = RES_G;
+            constexpr int WB2 = G * KC * (MT / 4) / NTHREADS;               // f32x4 of weights per thread and chunk (1 .. 4)
+            static_assert(G * KC * (MT / 4) % NTHREADS == 0, "whole sweeps");
+            float *Wl2 = smem, *Bl2 = smem + G * KC * MT;
+            const int ldb2 = p.ldb2;
+            // slot u of a thread: weight row u * RS + tid / (MT / 4) -- global and LDS offsets differ by wave-uniform constants
+            constexpr int RS = NTHREADS / (MT / 4);                       // rows per sweep of 256 threads
+            f32x4 wv[WB2];
+            const unsigned wgo0 = (unsigned)((tid / (MT / 4)) * p.Mpad + (tid % (MT / 4)) * 4), wlo0 = (unsigned)(tid * 4);
+            const unsigned wgs = (unsigned)(RS * p.Mpad);
+            BStage<NJ2, 2 * G> b2;
+            b2.setup(fa * V, span, p.Tres * V, lane);
+            auto issue2 = [&](int c0) {
+#pragma unroll
+                for (int u = 0; u < WB2; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)c0 * p.Mpad + (size_t)u * wgs + wgo0);
+                b2.issue(seg_base, p.Cres, cs, c0, wave);
+            };
+            auto commit2 = [&]() {
+#pragma unroll
+                for (int u = 0; u < WB2; ++u) *reinterpret_cast<f32x4 *>(Wl2 + u * (NTHREADS * 4) + wlo0) = wv[u];
+                b2.commit(Bl2, ldb2, wave);
+            };
+            issue2(0);
+            int c0 = 0;
+            for (; c0 + G * KC < p.CresPad; c0 += G * KC) {
+                __syncthreads();
+                commit2();
+                __syncthreads();
+                issue2(c0 + G * KC);
+                mfma_chunk<MT>(Wl2, Bl2, G, ldb2, KC * ldb2, offA, off[0], off[1], kh, acc);
+            }
             __syncthreads();
-            ws.commit(Wl);
-            bs.commit(Bl, p.ldb, wave);
+            commit2();
             __syncthreads();
-            ws.issue(wbase + (size_t)(c0 + KC) * p.Mpad);
-            bs.issue(seg_base, p.Cres, cs, c0 + KC, wave);
-            mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
+            mfma_chunk<MT>(Wl2, Bl2, G, ldb2, KC * ldb2, offA, off[0], off[1], kh, acc);
+            // (the epilogue operands are loaded BEHIND this chunk, not under it: 96 registers beside 8 staged rows would spill;
+            // one exposed load round trip per stride-2 tile of 200-400 us)
+            __builtin_amdgcn_sched_barrier(0);
+            if (OCC == 2) { load_half(0); load_half(1); }
         }
-        __syncthreads();
-        ws.commit(Wl);
-        bs.commit(Bl, p.ldb, wave);
-        __syncthreads();
-        if (OCC == 2) { load_half(0); load_half(1); }
-        mfma_chunk<MT>(Wl, Bl, 1, p.ldb, V, offA, off[0], off[1], kh, acc);
     }
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: + bias (+ identity residual), ReLU, predicated stores.
@@ -367,6 +406,7 @@ static int tcn_stage_impl(const float *y, const float *w, const float *x_res, co
     p.stamps = csk_diag_stamps();
     p.prio = !csk_diag_flag("CSK_NOPRIO");
     p.vec_stage = !csk_diag_flag("CSK_TCN_NOVEC");
+    p.no_peel_ct = csk_diag_flag("CSK_TCN_NOPEELCT");
     // 32-bit lane byte offsets: 4 * (4 * row_stride + position) must stay below 2^32
     p.fast_epi = (int64_t)p.Tres * V < (1ll << 27) && (int64_t)t_out * V < (1ll << 27) && !csk_diag_flag("CSK_SLOW_EPI");
     // the register staging holds <= 9 (128-row tiles) / 14 (64-row tiles) x 64 positions of an activation row -- the
@@ -403,7 +443,19 @@ static int tcn_stage_impl(const float *y, const float *w, const float *x_res, co
     }
     const int nj = (p.ldb + 63) / 64;
     if (nj > nj_max) CSK_FAIL("tcn_stage: activation tile of %d positions per channel exceeds the staged maximum (%d)", p.ldb, 64 * nj_max);
-    const size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
+    size_t lds = (size_t)(k * KC * MT + KC * p.ldb) * sizeof(float);
+    p.ldb2 = 4;
+    bool vt_ok = true;                     // the compile-time-V instantiations stage FOUR 8-channel groups per residual chunk
+    if (res_mode == CSK_RES_CONV) {
+        // conv-residual phase: G 8-channel groups per chunk (CresPad is a multiple of 16: G = 2 always divides it)
+        const int max_dt = (p.nt + V - 2) / V;
+        p.ldb2 = round_up((stride * max_dt + 1) * V, 4);
+        if (p.ldb2 > p.ldb) CSK_FAIL("tcn_stage: residual tile wider than the conv tile");
+        auto lds2 = [&](int G) { return (size_t)(G * KC * MT + G * KC * p.ldb2) * sizeof(float); };
+        vt_ok = p.CresPad % (4 * KC) == 0 && 2 * lds2(4) <= 160 * 1024;
+        const size_t need = lds2(vt_ok && k == 9 && (V == 25 || V == 18) ? 4 : 2);
+        if (need > lds) lds = need;
+    }
     if (lds > 160 * 1024) CSK_FAIL("tcn_stage: LDS tile %zu B exceeds 160 KiB", lds);
     const int Q = t_out * V;
     p.qtiles = (Q + p.nt - 1) / p.nt; p.mtiles = p.Mpad / MT;
@@ -418,6 +470,16 @@ static int tcn_stage_impl(const float *y, const float *w, const float *x_res, co
     if (k == 9 && !csk_diag_flag("CSK_TCN_NOK9"))     // the 9-tap form with straight-line 3-tap MFMA segments
         kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true> : tcn_stage_kernel<128, 9, true>)
                    : (nj <= 6 ? tcn_stage_kernel<64, 6, true> : nj <= 9 ? tcn_stage_kernel<64, 9, true> : tcn_stage_kernel<64, 14>);
+    // the two skeleton sizes of the reference's datasets (NTU-25, OpenPose-18) with V as a compile-time constant: the tap
+    // shift of an LDS read becomes an immediate offset (+0.1 ... +0.8 % per launch, in-process A/B CSK_TCN_NOVT)
+    if (k == 9 && (V == 25 || V == 18) && vt_ok && !csk_diag_flag("CSK_TCN_NOK9") && !csk_diag_flag("CSK_TCN_NOVT") && nj <= 9) {
+        if (V == 25)
+            kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true, false, 25> : tcn_stage_kernel<128, 9, true, false, 25>)
+                       : (nj <= 6 ? tcn_stage_kernel<64, 6, true, false, 25> : tcn_stage_kernel<64, 9, true, false, 25>);
+        else
+            kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true, false, 18> : tcn_stage_kernel<128, 9, true, false, 18>)
+                       : (nj <= 6 ? tcn_stage_kernel<64, 6, true, false, 18> : tcn_stage_kernel<64, 9, true, false, 18>);
+    }
     if (p.ksplit > 1) {
         if (nj > 9) CSK_FAIL("tcn_stage: the split-K form covers activation tiles of <= 576 positions per channel");
         kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true, true> : tcn_stage_kernel<128, 9, true, true>)

@@ -11,10 +11,12 @@ var, _, val = sys.argv[1].partition("=")
 val = val or "1"
 for b in sys.argv[2:]:
     os.environ[b] = "1"
-dev = "cuda:0"; A = pkg.ntu_graph().A
+dev = "cuda:0"
+V = int(os.environ.get("AB_V", "25")); NM = int(os.environ.get("AB_NM", "512"))
+A = (pkg.ntu_graph() if V == 25 else pkg.kinetics_graph()).A
 for (ci, co, s, t) in [(64, 64, 1, 300), (64, 128, 2, 300), (128, 128, 1, 150), (128, 256, 2, 150), (256, 256, 1, 75)]:
     blk = pkg.SpatioTemporalBlock(ci, co, A, stride=s).eval().to(dev)
-    x = torch.rand(512, ci, t, 25, device=dev); y = blk.gcn(x); ops = blk._packed_ops(x.device)
+    x = torch.rand(NM, ci, t, V, device=dev); y = blk.gcn(x); ops = blk._packed_ops(x.device)
     conv = ci != co or s != 1
     res = {0: [], 1: []}
     for rnd in range(12):

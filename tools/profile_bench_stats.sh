@@ -4,7 +4,7 @@
 # JSON line the same run printed (whose roofline.avg_launch_ms must agree with the tcn_stage_kernel rows).
 # usage: bash tools/profile_bench_stats.sh <tag>
 set -uo pipefail
-tag="${1:-r04}"
+tag="${1:-r05}"
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out="$R/gpurun_out/prof_$tag"
 mkdir -p "$out"
@@ -27,7 +27,7 @@ ro = d["roofline"]
 L += ["", f"Bench line of the same run: value {d['value']} {d['unit']}, ms_per_step {d['ms_per_step']}; roofline (HIP events around the "
       f"`tcn_stage_kernel` launches of the timed clip forwards): avg_launch_ms {ro.get('avg_launch_ms')}, achieved {ro['achieved']} TFLOP/s, frac {ro['frac']}.",
       "The `tcn_stage_kernel` rows above average over EVERY launch of the run (warm-up, A-GCN and bf16x3-leg launches of other shapes included);",
-      "the per-layer tables `r04_clip_layers.md` hold the timed-shape launches alone."]
+      "the per-layer tables `r05_clip_layers.md` hold the timed-shape launches alone."]
 open(f"{out}/bench_stats.md", "w").write("\n".join(L) + "\n")
 print("\n".join(L[:14]))
 PY

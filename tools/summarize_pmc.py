@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the PMC passes of tools/profile_r04.sh (gpurun_out/prof_<tag>/{sq,fetch,write}_<mode>) into
+"""Condense the PMC passes of tools/profile_r05.sh (gpurun_out/prof_<tag>/{sq,fetch,write}_<mode>) into
 profiles/<out>_pmc_summary.md: per kernel instantiation and precision mode -- launches, clock, MFMA-pipe busy fraction,
 waves per SIMD, wait fractions, HBM read / write MB per launch (FETCH_SIZE calibrated on input_norm_kernel, whose bytes
 are known: MI355X_MICROARCH.md HBM section) -- and refresh profiles/traffic_tcn_stage.json and traffic_tcn_step.json (what
@@ -48,7 +48,7 @@ def pmc(d, sub):
 
 def main(tag, out_tag):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    L = [f"# PMC passes ({out_tag}): tools/profile_r04.sh -- `rocprofv3 --kernel-trace --pmc ...` of tools/clip_pass.py (batch 256, both precision "
+    L = [f"# PMC passes ({out_tag}): tools/profile_r05.sh -- `rocprofv3 --kernel-trace --pmc ...` of tools/clip_pass.py (batch 256, both precision "
          "modes), tools/agcn_prof.py (A-GCN, Kinetics shape, batch 64) and tools/online_pass.py --shards 1 (the online shapes: CoST-GCN and "
          "CoAGCN, 1024 streams, 4-frame cycles); separate passes for SQ counters, FETCH_SIZE and WRITE_SIZE", ""]
     stage_entries = []
