@@ -209,3 +209,20 @@ def test_full_agcn_golden():
     check_parity(logits.cpu(), a["logits"])
     for i in (1, 5, 8, 10):
         check_parity(taps[i].cpu().reshape(-1)[::997], a[f"layer{i}_sub"])
+
+
+def test_agcn_clip_latency_mode_golden():
+    """AGcn.set_latency_mode: the temporal convs split their K loop (csk_tcn_stage_splitk_f32, V = 18), the adaptive graph
+    convs keep their kernels (no split form): fixture G8 within 1e-4, default mode restored bit for bit."""
+    a, sd, x = g8_state_dict()
+    net = pkg.AGcn(A_KIN, (3, 300, 18, 2), 400).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    base = net(x.to(DEV)).cpu()
+    net.set_latency_mode(4)
+    assert net.layers.layer6.clip_split_k == 4 and net.layers.layer6.gcn._clip_ksplit() == 1
+    lat = net(x.to(DEV)).cpu()
+    check_parity(lat, a["logits"], note="A-GCN latency mode vs G8")
+    check_parity(lat, base, note="A-GCN latency mode vs default (summation order)")
+    net.set_latency_mode(0)
+    assert torch.equal(net(x.to(DEV)).cpu(), base)
