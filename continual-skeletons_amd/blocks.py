@@ -141,19 +141,36 @@ def set_precision(module: nn.Module, precision: str = "f32") -> nn.Module:
     return module
 
 
-_SPLIT_SCRATCH = {}
+class SplitScratch:
+    """Partial-sum buffers of the split-K launches of the clip latency mode.  Owned by the module tree that
+    ``set_clip_latency_mode`` was called on (every block below shares one instance; a block whose ``clip_split_k`` was set
+    by hand gets one of its own) -- no module-global state.  One buffer per (device, HIP stream): launches on a stream are
+    ordered, so all layers reuse it.  A request larger than the current buffer allocates a new one and KEEPS the superseded
+    buffers alive: a captured hipGraph may hold their addresses.  ``release()`` drops them all (call it when no graph that
+    was captured in latency mode will be replayed again; ``set_clip_latency_mode(module, 0)`` does)."""
+
+    def __init__(self):
+        self._bufs = {}          # (device, stream handle) -> [buffers], newest (largest) last
+
+    def get(self, device, floats: int) -> torch.Tensor:
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        bufs = self._bufs.setdefault(key, [])
+        if not bufs or bufs[-1].numel() < floats:
+            bufs.append(torch.empty(int(floats), device=device, dtype=torch.float32))
+        return bufs[-1]
+
+    def release(self):
+        self._bufs.clear()
+
+    def nbytes(self) -> int:
+        return 4 * sum(b.numel() for bufs in self._bufs.values() for b in bufs)
 
 
-def split_scratch(device, floats: int) -> torch.Tensor:
-    """Partial-sum buffer of the split-K launches (clip latency mode): ONE growing buffer per (device, HIP stream) --
-    launches on a stream are ordered, so every layer can reuse it.  Under hipGraph capture the buffer must exist already
-    (run one eager forward first, as graph capture needs anyway)."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    buf = _SPLIT_SCRATCH.get(key)
-    if buf is None or buf.numel() < floats:
-        buf = torch.empty(int(floats), device=device, dtype=torch.float32)
-        _SPLIT_SCRATCH[key] = buf
-    return buf
+def _scratch_of(module) -> SplitScratch:
+    sc = module.__dict__.get("_split_scratch")
+    if sc is None:
+        sc = module.__dict__["_split_scratch"] = SplitScratch()
+    return sc
 
 
 def set_clip_latency_mode(module: nn.Module, split_k: int = 4, gcn_split_k: int = None) -> nn.Module:
@@ -172,16 +189,17 @@ def set_clip_latency_mode(module: nn.Module, split_k: int = 4, gcn_split_k: int 
     for v in (split_k, gcn_split_k):
         if not isinstance(v, int) or v < 0 or v > 32:
             raise ValueError("split_k must be an integer in [0, 32]")
-    hit = False
-    for m in module.modules():
-        if isinstance(m, SpatioTemporalBlock):
-            m.clip_split_k = split_k
-            hit = True
-        elif type(m) is GraphConvolution:
-            m.clip_split_k = gcn_split_k
-            hit = True
-    if not hit:
+    targets = [m for m in module.modules() if isinstance(m, SpatioTemporalBlock) or type(m) is GraphConvolution]
+    if not targets:
         raise ValueError("no SpatioTemporalBlock / GraphConvolution below this module: nothing to set")
+    # one partial-sum scratch for the whole tree (non-persistent, not part of state_dict); switching the mode off releases it
+    old = {id(sc): sc for sc in (m.__dict__.get("_split_scratch") for m in targets) if sc is not None}
+    for sc in old.values():
+        sc.release()
+    shared = SplitScratch() if max(split_k, gcn_split_k) > 1 else None
+    for m in targets:
+        m.clip_split_k = split_k if isinstance(m, SpatioTemporalBlock) else gcn_split_k
+        m.__dict__["_split_scratch"] = shared
     return module
 
 
@@ -247,7 +265,7 @@ class GraphConvolution(_Folded):
         ks = self._clip_ksplit()
         if ks > 1:
             self.stage(x, y, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v),
-                       ksplit=ks, partial=split_scratch(x.device, ks * n * self.out_channels * t * v))
+                       ksplit=ks, partial=_scratch_of(self).get(x.device, ks * n * self.out_channels * t * v))
             return y
         gcn_stage(x, y, ops, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v))
         return y
@@ -314,7 +332,7 @@ class TemporalConvolution(_Folded):
 
 
 def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=None, w_res=None, res_off=0, out=None,
-              split=False, ksplit=1):
+              split=False, ksplit=1, scratch=None):
     """csk_tcn_stage_f32, or with split=True csk_tcn_stage_bf16x3 (w / w_res are then the split operand images), or with
     ksplit > 1 csk_tcn_stage_splitk_f32 (clip latency mode: K loop cut into channel ranges, partial sums in split order)."""
     n, c, t_in, v = y.shape
@@ -327,7 +345,9 @@ def tcn_stage(y, w, bias, c_out, k, stride, pad, relu=True, res_mode=0, x_res=No
         raise RuntimeError(f"out must be a contiguous float32 {(n, c_out, t_out, v)} tensor on {y.device}")
     c_res, t_res = (x_res.shape[1], x_res.shape[2]) if x_res is not None else (0, 0)
     if ksplit > 1 and not split:
-        part = split_scratch(y.device, ksplit * n * c_out * t_out * v)
+        if scratch is None:
+            raise RuntimeError("tcn_stage: ksplit > 1 needs the owning module's SplitScratch")
+        part = scratch.get(y.device, ksplit * n * c_out * t_out * v)
         rc = native.lib().csk_tcn_stage_splitk_f32(
             native.ptr(y), native.ptr(w), native.ptr(x_res), native.ptr(w_res), native.ptr(bias), native.ptr(out),
             n, c, c_out, t_in, v, k, stride, pad, res_mode, c_res, t_res, res_off, int(relu), ksplit, native.ptr(part),
@@ -405,7 +425,8 @@ class SpatioTemporalBlock(_Folded):
                              res_mode=mode, x_res=xr, w_res=ops["w_res_split"], res_off=shrink, out=out, split=True)
         ks = max(1, min(self.clip_split_k, -(-ops["c"] // 8))) if (self.clip_split_k > 1 and ops["k"] == 9) else 1
         return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
-                         res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out, ksplit=ks)
+                         res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out, ksplit=ks,
+                         scratch=_scratch_of(self) if ks > 1 else None)
 
 
 def tcn_step_launch(*args):

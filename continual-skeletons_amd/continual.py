@@ -261,15 +261,14 @@ class CoSpatioTemporalBlock(SpatioTemporalBlock):
 
     split_k = 0     # 0: no split-K; n > 1: latency mode -- up to n channel ranges per tile when a launch is too small
 
-    THROUGHPUT_SPLIT_K = 3   # split-K of the 256-channel blocks (see _pick_ksplit)
+    THROUGHPUT_SPLIT_K = 1   # split-K of the 256-channel blocks in the default mode (see _pick_ksplit)
 
     def _pick_ksplit(self, p: int) -> int:
         """Split-K factor of this block's TCN step (csk_tcn_step_f32 ``ksplit``) -- a function of (C_out, split_k) ONLY: a
         stream's results never depend on how many streams share the slab (``p`` is not used).
-        * Blocks with C_out >= 256 always cut their 2304-deep K loop into 3 channel ranges: their tiles are the longest
-          of the stack (128 x 128 x 2304) and come 400-800 per launch for 512 resident slots; three times as many tiles a
-          third as long pack the GPU better (measured at 1024 streams, two shards, 4 frames per launch: 954 k -> 966 k /
-          980 k / 965 k frames/s for 2 / 3 / 4 splits; splitting the 128-channel blocks as well: 944 k).
+        * Default mode: no split.  (Rounds 2-5 cut the 2304-deep K loop of the C_out >= 256 blocks into 3 channel ranges to
+          pack 800 tiles of 128 x 128 onto 512 resident slots; the slot-balanced tiles of csrc/step16.hip make every launch
+          of the 1024-stream cycle exactly 512 equal workgroups, without partial sums and a reduction launch.)
         * Latency mode (``split_k`` > 1, meant for a handful of streams): up to 4 * split_k ranges (<= 32), at least one
           8-channel chunk each -- a 9-tap chunk is 3.8 us of MFMAs for one workgroup, and with a handful of tiles the other
           250 CUs are idle anyway.  (Until round 4 the factor was also capped by 256 // tiles, i.e. by the slab size: one
@@ -522,6 +521,12 @@ class CoStGcn(_Folded):
             cum *= self.layers[f"layer{i + 1}"].stride
             emits.append(max(1, MAX_CYCLE // cum))
         need = max(self.layers[f"layer{i + 1}"].scratch_floats(p, emits[i], recv[i]) for i in range(10))
+        if need * 4 > self.LATENCY_SCRATCH_CAP_BYTES:
+            raise RuntimeError(
+                f"set_latency_mode({self.layers.layer1.split_k}) on a slab of {n} streams needs a {need * 4 / 1e9:.2f} GB split-K "
+                f"scratch (cap {self.LATENCY_SCRATCH_CAP_BYTES / 1e9:.1f} GB): the latency mode splits every K loop into up to 32 "
+                "channel ranges whatever the slab size -- it is meant for a handful of streams; use the default mode "
+                "(set_latency_mode(0)) for slabs that fill the GPU")
         self._scratch = torch.empty((need,), device=device, dtype=torch.float32) if need else None
         for i in range(10):
             out_slots = in_slots(recv[i + 1]) if i < 9 else max(4, emits[i])
@@ -534,6 +539,8 @@ class CoStGcn(_Folded):
         self._flushed = False
         self._build_plan(device)
 
+    LATENCY_SCRATCH_CAP_BYTES = 1 << 30   # split-K scratch above which binding a slab in latency mode is refused
+
     def set_latency_mode(self, split_k: int = 8):
         """Few-stream operation (one camera, a handful of streams): the TCN step of a block then holds one workgroup
         per tile that walks all 9*C/8 K-chunks alone (123 us at C = 256).  With ``split_k`` > 1 such launches cut the
@@ -541,7 +548,9 @@ class CoStGcn(_Folded):
         (csk_tcn_step_f32 ``ksplit``); launches that fill the GPU anyway are left alone.  Results differ from the
         default by fp32 summation order only.  Takes effect from a clean state (the slab is re-bound).  (Replaying a
         frame's launches from hipGraphs was built and measured slower than eager launches on ROCm 7.2 -- 0.41 vs 0.36 ms per
-        frame-step -- and removed: profiles/HISTORY.md.)"""
+        frame-step -- and removed: profiles/HISTORY.md.)  The split factor does not shrink with the slab (a stream's bits must
+        not depend on its neighbours), so the scratch grows with it: binding a slab whose scratch would exceed
+        LATENCY_SCRATCH_CAP_BYTES (1 GiB: about 300 NTU streams at split_k = 8) raises instead of silently running slower than the default mode."""
         for i in range(10):
             self.layers[f"layer{i + 1}"].split_k = int(split_k)
         self._n = None

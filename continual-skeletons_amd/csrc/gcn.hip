@@ -829,6 +829,10 @@ static int gcn_stage_impl(const float *x, float *y, const float *w, const float 
         p.cper = round_up((p.CinPad + ksplit - 1) / ksplit, 8);
         p.ksplit = (c_in + p.cper - 1) / p.cper;
     }
+    if (sparse && p.ksplit == 1) {     // slot-balanced 16x16x4 tiles where they pack the chip better (step16.hip; same sums)
+        const int rc = csk_launch_gcn16(p, n_seg, stream);
+        if (rc != -2) return rc;
+    }
     if (sparse) {
         const int R = p.R;
         size_t lds2;

@@ -27,3 +27,7 @@ struct GcnParams {
 // gcn_dense.hip: dense (per-segment or per-frame) adjacency with an even joint count V <= 18; returns -2 when the shape is
 // not one it is built for (the caller then uses the kernels of gcn.hip), otherwise the launch status
 int csk_launch_gcn_dense2(GcnParams p, int n_seg, void *stream);
+
+// step16.hip: the slot-balanced 16x16x4 tiles for skeleton-sparse adjacencies on 16-byte-aligned layouts; -2 when the shape is
+// not supported or the 32x32x2 kernels pack the chip as well (bitwise the same results either way)
+int csk_launch_gcn16(GcnParams p, int n_seg, void *stream);

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "mfma_core.h"
+#include "step_params.h"
 
 // ------------------------------------------------------------------------------------------------
 // ring staging: NS ring slots x KC channel rows x NP positions -> Bl [slot][KC][NP]
@@ -82,18 +83,6 @@ struct RingStage {
     }
 };
 
-struct StepParams {
-    const float *ring, *w, *xres, *wres, *bias;     // xres / out are RING bases; slots are picked per emission
-    float *out;
-    int C, Cpad, Cout, Mpad, K, slots, head, head_step;
-    int res_mode, Cres, CresPad, relu;
-    int xres_slots, xres_slot0, xres_step, out_slots, out_slot0;
-    int fast_epi;      // P fits the 32-bit lane byte offsets of the scalar-base epilogue addressing
-    unsigned gx, gy, gz;   // position tiles, m-tiles, emission groups [* ksplit] of the launch (the grid is 1-D)
-    int ksplit, cper;  // split-K (latency mode): emission groups * ksplit slices, split ks covers channels [ks*cper, ..+cper)
-    float *part;       // and writes raw partial sums to part[(emission*ksplit + ks)][Cout][P]; 1 = off
-    int64_t P;
-};
 
 // E = emissions per workgroup tile (folded into the tile's column axis, see RingStage), HS = head_step of the launch
 // (1, or 2 for a stride-2 block; only meaningful for E > 1).  SPLIT = false is the throughput kernel; the split-K form
@@ -637,6 +626,12 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     p.ksplit = ksplit > 1 ? (c + p.cper - 1) / p.cper : 1;
     p.part = partial;
     if (p.ksplit > 1 && ((uintptr_t)partial & 15)) CSK_FAIL("tcn_step: partial-sum buffer must be 16-byte aligned");
+    // the slot-balanced 16x16x4 tiles (step16.hip) where the launch shape packs the resident workgroup slots better with
+    // them; bitwise the same results (-2: not taken)
+    if (p.ksplit == 1) {
+        const int rc = csk_launch_tcn_step16(p, n_emit, stream);
+        if (rc != -2) return rc;
+    }
     const bool big = (p.Mpad % 128) == 0;
     const int MT = big ? 128 : 64, NT = 16384 / MT;
     // emissions folded into a workgroup tile: the largest E in {4, 2, 1} that divides n_emit and leaves >= 64 positions
@@ -719,6 +714,24 @@ extern "C" int csk_co_block_step_f32(const float *xin, int xin_slots, int xin_sl
     p.V = V; p.n_skel = n_skel; p.vmagic = vmagic_of(V); p.fast_epi_g = t.fast_epi;
     p.ldbx = round_up(((NP + V - 2) / V + 1) * V, 4);
     if (p.ldbx > 128) CSK_FAIL("co_block_step: %d joints per skeleton make the input strip of a 64-position tile longer than 128", V);
+    // With the slot-balanced tile family (step16.hip) the cycle is its two launches: the family's temporal step has its own
+    // fp32 summation order, and a block must give the same bits whether its frames arrive one by one or four at a time
+    if (csk_step16_enabled()) {
+        for (int f = 0; f < 4;) {                              // one graph-conv launch per non-wrapping slot run
+            const int xs = (xin_slot0 + f) % xin_slots, ys = (y_slot0 + f) % y_slots;
+            int run = 4 - f;
+            if (run > xin_slots - xs) run = xin_slots - xs;
+            if (run > y_slots - ys) run = y_slots - ys;
+            if (const int rc = csk_gcn_stage_f32(xin + (int64_t)xs * c_in * P, y_ring + (int64_t)ys * c_out * P, gcn_w, gcn_bias, ell_src,
+                                                 ell_val, ell_cnt, ell_w, 0, 0, run, c_in, c_out, n_skel, V, (int64_t)c_in * P, P,
+                                                 (int64_t)c_out * P, P, gcn_res_mode, stream))
+                return rc;
+            f += run;
+        }
+        return csk_tcn_step_f32(y_ring, y_slots, y_slot0, 1, 4, tcn_w, res_mode ? xin : nullptr, xin_slots, x_res_slot0, 1, nullptr,
+                                tcn_bias, out, out_slots, out_slot0, c_out, c_out, P, 9, res_mode, res_mode ? c_in : 0, 1, 1, nullptr,
+                                stream);
+    }
     const int R = gcn_res_mode == CSK_RES_CONV ? 4 : 3;
     const size_t lds_g = 2 * (size_t)(R * 8 * 64 + 4 * 8 * p.ldbx), lds_t = (size_t)(9 * KC * 64) + RingStage<64, 12>::LDS_FLOATS;
     const size_t lds = (lds_g > lds_t ? lds_g : lds_t) * sizeof(float);

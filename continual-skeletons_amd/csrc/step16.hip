@@ -1,0 +1,548 @@
+// step16.hip -- slot-balanced tiles for the continual (frame-by-frame) path: v_mfma_f32_16x16x4_f32 kernels whose workgroup
+// tile is 64 output channels x 16*NB columns, NB = 25 (NTU, V = 25) or 18 (Kinetics, V = 18).
+//
+// Why a second tile family.  One frame of 1024 NTU streams is P = 51 200 positions = 800 x 64: every 32x32x2 tile shape of
+// step.hip / gcn.hip cuts a launch into 800 k tiles for 512 (or 768) resident workgroup slots -- 1.56 (1.04) rounds, i.e. a
+// last round that is 56 % (4 %) full on EVERY launch of the cycle (profiles/r05_online_1shard.md: 0.49-0.63 of the fp32 MFMA
+// peak where the same tiles reach 0.77-0.83 in the many-round clip launches).  P = 512 x 100, and 100 positions x E emissions
+// is 25 column blocks of 16 when E = 4 (C_out = 64), 200 x 2 when E = 2 (C_out = 128, two m-tiles), 400 x 1 when E = 1
+// (C_out = 256, four m-tiles): with 16-wide MFMA blocks every launch of the cycle is EXACTLY 512 workgroups of equal work =
+// one full round at two workgroups per CU (Kinetics: P = 512 x 72, NB = 18).  v_mfma_f32_16x16x4_f32 has the rate of
+// v_mfma_f32_32x32x2_f32 (64 FLOP / clk / SIMD, MI355X_MICROARCH.md) and is the same fmaf chain in ascending k
+// (tools/microbench/mfma16_order_probe.hip), so the kernels here are BITWISE interchangeable with the ones they stand in
+// for: the K loop visits (chunk, tap, channel) in the same order, the epilogue is the same expression.  Which family a
+// launch gets is therefore a pure throughput policy of the launch shape (csk_step16_wins below).
+//
+// Wave tile: a wave owns 16 output channels (wave w: rows 16 w ..) and ALL NB column blocks: 4 NB accumulator registers.
+// The MFMA is issued "transposed" -- A = activations (16 positions x 4 channels), B = weights (4 channels x 16 output
+// channels) -- so that a lane's 4 accumulator registers are 4 CONSECUTIVE POSITIONS of one output channel: residual loads and
+// output stores are 16-byte accesses without a cross-lane transpose.
+//
+// LDS window: for an input channel the staged ring slots lie BACK TO BACK in one row (slot w at w * NP), so column
+// c = j * NP + p of tap r (emission j reads slot j + r) is at  r * NP + c : affine in the column, every fragment read is one
+// VGPR base + an immediate offset.  Stride-2 launches (emission j reads slot 2 j + r) keep the even and the odd slots in two
+// such runs.  Row strides are = 16 (mod 32) floats: the four k-slots of a fragment read hit disjoint banks.
+#include "mfma_core.h"
+#include "gcn_params.h"
+#include "step_params.h"
+
+namespace {
+
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+constexpr int row16(int n) { return ((n - 16 + 31) / 32) * 32 + 16; }   // smallest stride >= n that is 16 (mod 32)
+
+template <int NB, int E, int HS>
+struct G16 {
+    static constexpr int KCH = 4;                       // channels per chunk of the temporal phase = one MFMA k-step per tap
+    static constexpr int KR = 8;                        // channels per chunk of the residual-conv phase
+    static constexpr int NT = 16 * NB, NP = NT / E, Q = NP / 4;
+    static_assert(NT % E == 0 && NP % 4 == 0, "an emission's positions are whole 16-byte quads");
+    static constexpr int NS = 8 + (E - 1) * HS + 1;     // window slots (K = 9)
+    static constexpr int NEV = (NS + 1) / 2;            // even slots (stride-2 layout)
+    static constexpr int ROW = row16(NS * NP);
+    static constexpr int ROWR = row16(NT);
+    static constexpr int LDW = 80;                      // weight row stride: 64 output channels, 16 (mod 32)
+    static constexpr int WSZ = 9 * KCH * LDW;
+    static constexpr int LDS_FLOATS = imax(WSZ + KCH * ROW, KR * LDW + KR * ROWR);
+    // LDS offset of window slot w inside a channel row; tap r of emission j is at slot_lds(r) + j * NP
+    static constexpr int slot_lds(int w) { return HS == 2 ? ((w & 1) ? (NEV + (w >> 1)) * NP : (w >> 1) * NP) : w * NP; }
+};
+
+// Staging of KCHX channel rows x NSL ring slots x NP positions (register prefetch: issue = global -> registers, commit =
+// registers -> LDS).  Unit e of the (channel, slot, quad) space, quad fastest; a thread owns units sweep * 256 + tid.
+template <int KCHX, int NSL, int NP, int ROWX, bool EVENODD>
+struct Win16 {
+    static constexpr int Q = NP / 4, U = KCHX * NSL * Q, NSW = (U + NTHREADS - 1) / NTHREADS, NEV = (NSL + 1) / 2;
+    static_assert(KCHX * ROWX * 4 < 65536, "LDS byte offsets are packed two to a register");
+    unsigned goff[NSW];            // byte offset from (ring + c0 * P + p0): the ring is < 4 GB (checked by the launcher)
+    unsigned loff2[(NSW + 1) / 2]; // LDS byte offsets of sweeps 2 i (low half) and 2 i + 1 (high half)
+    f32x4 v[NSW];
+    // slot w of the window = slot (first + w * step) % slots of the source (slot_stride floats apart, channel rows chan_stride
+    // apart); pmax = last legal f32x4 start relative to the tile's first position
+    __device__ __forceinline__ void setup(int first, int step, int slots, int64_t slot_stride, int64_t chan_stride, int pmax, int tid) {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            const int e = min(u * NTHREADS + tid, U - 1);
+            const int i = e % Q, rw = e / Q, w = rw % NSL, kk = rw / NSL;
+            const int64_t so = (int64_t)((first + w * step) % slots) * slot_stride + (int64_t)kk * chan_stride + min(4 * i, pmax);
+            goff[u] = (unsigned)(so * 4);
+            const int sl = EVENODD ? ((w & 1) ? (NEV + (w >> 1)) * NP : (w >> 1) * NP) : w * NP;
+            const unsigned lo = (unsigned)(kk * ROWX + sl + 4 * i) * 4u;
+            if (u & 1) loff2[u / 2] |= lo << 16;
+            else loff2[u / 2] = lo;
+        }
+    }
+    // The load address is a wave-uniform base (scalar registers) + one 32-bit lane offset; the empty asm keeps the compiler
+    // from folding the loop-invariant part of the base into a 64-bit per-lane address held across the K loop.
+    template <int U0, int U1>
+    __device__ __forceinline__ void issue_range(const float *__restrict__ base) {
+#pragma unroll
+        for (int u = U0; u < U1; ++u) {
+            unsigned g = goff[u];
+            asm volatile("" : "+v"(g));
+            v[u] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + g);
+        }
+    }
+    template <int G>
+    __device__ __forceinline__ void issue_third(const float *__restrict__ base) { issue_range<G * NSW / 3, (G + 1) * NSW / 3>(base); }
+    __device__ __forceinline__ void issue(const float *__restrict__ base) { issue_range<0, NSW>(base); }
+    // chunk whose channels c0 .. c0 + KCHX - 1 reach past C: rows >= C are read from row C - 1 and zeroed (their weights are
+    // zero as well; the product must not be 0 x Inf)
+    __device__ __forceinline__ void issue_tail(const float *__restrict__ base, int c0, int C, int64_t chan_stride, int tid) {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            const int e = min(u * NTHREADS + tid, U - 1);
+            const int kk = (e / Q) / NSL;
+            const int over = max(c0 + kk - (C - 1), 0);
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + goff[u] - (size_t)over * chan_stride * 4);
+            v[u] = x * (over ? 0.f : 1.f);
+        }
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Bl) const {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            const unsigned lo = (u & 1) ? loff2[u / 2] >> 16 : loff2[u / 2] & 0xffffu;
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(Bl) + lo) = v[u];
+        }
+    }
+};
+
+// weights: NTAPS x KCHX channel rows x 64 output channels of the packed [tap][Cpad][Mpad] layout -> Wl[(r * KCHX + kk)][LDW];
+// ENTRY: rows in the graph conv's k order instead (gcn_entry below)
+__host__ __device__ constexpr int gcn_entry(int kk, int r, int R) { return ((kk >> 1) * R + r) * 2 + (kk & 1); }
+template <int NTAPS, int KCHX, int LDW, bool ENTRY = false>
+struct W16 {
+    static constexpr int U = NTAPS * KCHX * 16, NSW = (U + NTHREADS - 1) / NTHREADS;
+    unsigned goff[NSW], loff[NSW];
+    f32x4 v[NSW];
+    __device__ __forceinline__ void setup(int Cpad, int Mpad, int tid) {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            const int e = min(u * NTHREADS + tid, U - 1);
+            const int row = e / 16, m4 = e % 16, r = row / KCHX, kk = row % KCHX;
+            goff[u] = (unsigned)(((r * Cpad + kk) * Mpad + m4 * 4) * 4);
+            loff[u] = (unsigned)((ENTRY ? gcn_entry(kk, r, NTAPS) : row) * LDW + m4 * 4);
+        }
+    }
+    __device__ __forceinline__ void issue_one(int u, const float *__restrict__ base) {
+        if (u < NSW) {
+            unsigned g = goff[u];
+            asm volatile("" : "+v"(g));
+            v[u] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + g);
+        }
+    }
+    __device__ __forceinline__ void issue(const float *__restrict__ base) {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) issue_one(u, base);
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Wl) const {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) *reinterpret_cast<f32x4 *>(Wl + loff[u]) = v[u];
+    }
+};
+
+// one tap (one k-step of 4 channels): acc[cb] += act[16 cb .. + 15][k] x w[k][16 channels]
+template <int NB>
+__device__ __forceinline__ void mfma16_tap(const float *__restrict__ wl, const float *__restrict__ bl, f32x4 (&acc)[NB]) {
+    const float wf = wl[0];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bl[16 * cb], wf, acc[cb], 0, 0, 0);
+}
+
+// Epilogue shared by the kernels of this file: out = [ReLU](acc + bias + identity residual).  A lane holds positions
+// 16 cb + 4 kq .. + 3 (columns = NSLOT slots x NP positions, slot-major) of output channel `ch` for every column block: 16-byte
+// residual loads and stores.  Slot bases are wave-uniform byte offsets (the rings are < 4 GB); the slot of a column block is a
+// compile-time constant except for the blocks that straddle a slot boundary.  Column blocks go in groups of EG: the group's
+// residual loads are in flight together.  nrow = positions of the tile that lie inside the channel row (a multiple of 4: what
+// may be loaded), nval = positions that are stored (<= nrow; a quad that straddles nval is stored element by element).
+template <int NB, int NSLOT, int NP>
+__device__ __forceinline__ void epilogue16(f32x4 (&acc)[NB], const float *__restrict__ bias_p, int Cout, int ch, int kq, bool ident, bool relu,
+                                           const float *__restrict__ xres, float *__restrict__ out, const unsigned (&xslot)[NSLOT],
+                                           const unsigned (&oslot)[NSLOT], int64_t x_chan_stride, int64_t o_chan_stride, int p0, int nrow,
+                                           int nval) {
+    const bool chv = ch < Cout;
+    const int chc = min(ch, Cout - 1);
+    const float bias = bias_p[chc];
+    const unsigned xrow = (unsigned)(((int64_t)chc * x_chan_stride + p0) * 4), orow = (unsigned)(((int64_t)chc * o_chan_stride + p0) * 4);
+    const int pmax = nrow - 4;
+    constexpr int EG = 5, NG = (NB + EG - 1) / EG;
+    // group g + 1's residual loads are issued in front of group g's arithmetic and stores (two groups of registers)
+    f32x4 rv[2][EG];
+    unsigned oo[2][EG];
+    int left[2][EG];                                         // stored positions from the quad's first on (<= 0: none)
+    auto load_group = [&](int g, int b) {
+#pragma unroll
+        for (int u = 0; u < EG; ++u) {
+            const int cb = g * EG + u;
+            if (cb >= NB) continue;
+            const int c = 16 * cb + 4 * kq;                  // first column of this lane's quad: slot j, position pp
+            int j = 0;
+#pragma unroll
+            for (int jj = 1; jj < NSLOT; ++jj) j += (c >= jj * NP) ? 1 : 0;
+            const int pp = c - j * NP;
+            unsigned os = oslot[0], xs = xslot[0];
+#pragma unroll
+            for (int jj = 1; jj < NSLOT; ++jj) { os = (j == jj) ? oslot[jj] : os; xs = (j == jj) ? xslot[jj] : xs; }
+            left[b][u] = chv ? nval - pp : 0;
+            const unsigned po = 4u * (unsigned)max(min(pp, pmax), 0);
+            oo[b][u] = os + orow + po;
+            rv[b][u] = ident ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(xres) + (xs + xrow + po)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_group(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int b = g & 1;
+        if (g + 1 < NG) load_group(g + 1, b ^ 1);
+#pragma unroll
+        for (int u = 0; u < EG; ++u) {
+            const int cb = g * EG + u;
+            if (cb >= NB) continue;
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = acc[cb][q] + bias + rv[b][u][q];
+                o[q] = relu ? relu_nan(v) : v;
+            }
+            float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(out) + oo[b][u]);
+            if (left[b][u] >= 4) *reinterpret_cast<f32x4 *>(dst) = o;
+            else if (left[b][u] > 0) {                       // the quad straddles the last stored position
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < left[b][u]) dst[q] = o[q];
+            }
+        }
+    }
+}
+
+// TAIL: channel counts that are not whole chunks (C % 4, C_res % 8): the chunk that reaches past C is staged with clamped,
+// zeroed rows (uniform branches in the K loop); the fast instantiation has none.
+template <int NB, int E, int HS, bool TAIL>
+__global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(const StepParams p) {
+    typedef G16<NB, E, HS> G;
+    constexpr int KCH = G::KCH, NP = G::NP, ROW = G::ROW, LDW = G::LDW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem, *Bl = smem + G::WSZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    // XCD-contiguous work order, m-tile fastest (the m-tiles of a position tile read the same ring window)
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int by = (int)(wid % p.gy), bz = (int)((wid / p.gy) % p.gz), bx = (int)(wid / (p.gy * p.gz));
+    const int m0 = by * 64, p0 = bx * NP, j0 = bz * E;
+    const int64_t P = p.P;
+    int first = (p.head + j0 * p.head_step - 8) % p.slots;                     // ring slot of window slot 0
+    if (first < 0) first += p.slots;
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment bases: weights (B operand) lane (n = l15 -> output channel, k = kq), activations (A operand) lane (i = l15 ->
+    // position inside the column block, k = kq)
+    const float *wl_lane = Wl + kq * LDW + wave * 16 + l15;
+    const float *bl_lane = Bl + kq * ROW + l15;
+    {   // ---- phase 1: temporal conv over the ring window
+        W16<9, KCH, LDW> ws;
+        Win16<KCH, G::NS, NP, ROW, HS == 2> rs;
+        ws.setup(p.Cpad, p.Mpad, tid);
+        rs.setup(first, 1, p.slots, (int64_t)p.C * P, P, (int)(P - 4 - p0), tid);
+        const float *wbase = p.w + m0;
+        const float *rbase = p.ring + p0;
+        ws.issue(wbase);
+        if (TAIL && KCH > p.C) rs.issue_tail(rbase, 0, p.C, P, tid);
+        else rs.issue(rbase);
+        for (int c0 = 0; c0 < p.Cpad; c0 += KCH) {
+            __syncthreads();
+            ws.commit(Wl);
+            rs.commit(Bl);
+            __syncthreads();
+            // next chunk's loads in three bursts between the three tap segments; past the end the last chunk is loaded again
+            // into the (then dead) staging registers so that the K loop stays one basic block
+            const int cn = min(c0 + KCH, p.Cpad - KCH);
+            const float *wnext = wbase + (size_t)cn * p.Mpad, *rnext = rbase + (int64_t)cn * P;
+            const bool tail = TAIL && cn + KCH > p.C;                           // uniform
+            ws.issue_one(0, wnext);
+            if (!tail) rs.template issue_third<0>(rnext);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) mfma16_tap<NB>(wl_lane + r * KCH * LDW, bl_lane + G::slot_lds(r), acc);
+            __builtin_amdgcn_s_setprio(0);
+            ws.issue_one(1, wnext);
+            if (!tail) rs.template issue_third<1>(rnext);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int r = 3; r < 6; ++r) mfma16_tap<NB>(wl_lane + r * KCH * LDW, bl_lane + G::slot_lds(r), acc);
+            __builtin_amdgcn_s_setprio(0);
+            ws.issue_one(2, wnext);
+            if (!tail) rs.template issue_third<2>(rnext);
+            else rs.issue_tail(rnext, cn, p.C, P, tid);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int r = 6; r < 9; ++r) mfma16_tap<NB>(wl_lane + r * KCH * LDW, bl_lane + G::slot_lds(r), acc);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    // ---- phase 2: 1x1 residual conv on the delayed block input (one "tap" per emission: the E residual frames back to back)
+    if (p.res_mode == CSK_RES_CONV) {
+        constexpr int KR = G::KR, ROWR = G::ROWR;
+        float *Wr = smem, *Br = smem + KR * LDW;
+        W16<1, KR, LDW> ws;
+        Win16<KR, E, NP, ROWR, false> rs;
+        ws.setup(p.CresPad, p.Mpad, tid);
+        rs.setup((p.xres_slot0 + j0 * p.xres_step) % p.xres_slots, p.xres_step, p.xres_slots, (int64_t)p.Cres * P, P, (int)(P - 4 - p0), tid);
+        const float *wbase = p.wres + m0;
+        const float *xbase = p.xres + p0;
+        const float *wr_lane = Wr + kq * LDW + wave * 16 + l15;
+        const float *br_lane = Br + kq * ROWR + l15;
+        ws.issue(wbase);
+        if (TAIL && KR > p.Cres) rs.issue_tail(xbase, 0, p.Cres, P, tid);
+        else rs.issue(xbase);
+        for (int c0 = 0; c0 < p.CresPad; c0 += KR) {
+            __syncthreads();
+            ws.commit(Wr);
+            rs.commit(Br);
+            __syncthreads();
+            const int cn = min(c0 + KR, p.CresPad - KR);
+            ws.issue(wbase + (size_t)cn * p.Mpad);
+            if (TAIL && cn + KR > p.Cres) rs.issue_tail(xbase + (int64_t)cn * P, cn, p.Cres, P, tid);
+            else rs.issue(xbase + (int64_t)cn * P);
+#pragma unroll
+            for (int s = 0; s < KR / 4; ++s) mfma16_tap<NB>(wr_lane + 4 * s * LDW, br_lane + 4 * s * ROWR, acc);
+        }
+    }
+    // ---- epilogue: + bias (+ identity residual), ReLU
+    unsigned oslot[E], xslot[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        oslot[j] = (unsigned)((int64_t)((p.out_slot0 + j0 + j) % p.out_slots) * p.Cout * P * 4);
+        xslot[j] = (unsigned)((int64_t)((p.xres_slot0 + (j0 + j) * p.xres_step) % p.xres_slots) * p.Cres * P * 4);
+    }
+    const int nval = (int)min((int64_t)NP, P - p0);                             // positions of the tile inside the row (multiple of 4)
+    epilogue16<NB, E, NP>(acc, p.bias, p.Cout, m0 + wave * 16 + l15, kq, p.res_mode == CSK_RES_IDENTITY, p.relu != 0, p.xres, p.out,
+                          xslot, oslot, P, P, p0, nval, nval);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Graph conv on the same tiles (csk_gcn_stage_f32 for skeleton-sparse adjacencies, <= 1 / 1 / 4 non-zeros per column):
+//     y[f][co][q] = ReLU( sum_r sum_c W_r[c][co] * agg_r(x_f)[c][q] + bias[co] + gcn_residual )
+// Tile = 64 output channels x (F segments x NPG positions), NPG a multiple of V: a tile holds WHOLE skeletons, so the raw input
+// chunk of the tile's own columns is all the aggregation needs.  Per 8-channel chunk:
+//   P1  every thread aggregates its <= 2 columns for the 8 channels from the staged x rows (adjacency entries in registers,
+//       the expression of gcn_stage_sparse2_kernel) into LDS rows in the K ORDER of that kernel -- (channel pair s, subset r,
+//       channel 2 s + h) -> row (s R + r) 2 + h -- and commits the chunk's weights in the same row order;
+//   P2  the MFMAs walk the rows four at a time (the chain of the 32x32x2 kernel's k-step pairs: bitwise the same sums); the
+//       next chunk's x rows are committed and the one after is loaded underneath.
+// Two barriers per chunk, x single-buffered (read in P1, rewritten in P2).
+template <int NB, int F, bool CONVRES, bool TAIL>
+__global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void gcn16_kernel(const GcnParams p) {
+    constexpr int R = CONVRES ? 4 : 3, KCG = 8, NE = KCG * R;
+    constexpr int NT = 16 * NB, NPG = NT / F, AROW = row16(NT), XROW = NT, LDW = 80;
+    constexpr int NCOL = (NT + NTHREADS - 1) / NTHREADS;               // columns aggregated per thread
+    static_assert(NT % F == 0 && NPG % 4 == 0, "a segment's positions are whole 16-byte quads");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem, *Ba = smem + NE * LDW, *Xs = Ba + NE * AROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int mt = (int)(wid % p.mtiles), qt = (int)((wid / p.mtiles) % p.qtiles), sg = (int)(wid / (p.mtiles * p.qtiles));
+    const int m0 = mt * 64, q0 = qt * NPG, seg0 = sg * F;
+    const int V = p.V, Q = p.frames * V;
+    const int nval = min(NPG, Q - q0);                                 // valid positions of the tile: whole skeletons
+    // adjacency entries of this thread's columns (offsets inside an x row of the tile)
+    int eoff[NCOL][6], ioff[NCOL], acol[NCOL];
+    float eval[NCOL][6];
+#pragma unroll
+    for (int n = 0; n < NCOL; ++n) {
+        const int col = min(n * NTHREADS + tid, NT - 1);
+        const int f = col / NPG, pos = min(col - f * NPG, nval - 1);
+        const int t = div_magic(pos, p.vmagic), w = pos - t * V, sb = f * NPG + t * V;
+        acol[n] = col;
+        ioff[n] = sb + w;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;          // subsets 0,1: one entry; subset 2: four
+            const bool have = k < p.ell_cnt[r];
+            const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
+            eoff[n][e] = sb + (have ? p.ell_src[idx] : 0);
+            eval[n][e] = have ? p.ell_val[idx] : 0.f;
+        }
+    }
+    f32x4 acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    W16<R, KCG, LDW, true> ws;
+    Win16<KCG, F, NPG, XROW, false> xs;
+    ws.setup(p.CinPad, p.Mpad, tid);
+    xs.setup(0, 1, 1 << 30, p.x_seg_stride, p.x_chan_stride, (int)(p.x_chan_stride - 4 - q0), tid);
+    const float *wbase = p.w + m0;
+    const float *xbase = p.x + (int64_t)seg0 * p.x_seg_stride + q0;
+    const float *wl_lane = Wl + kq * LDW + wave * 16 + l15;
+    const float *ba_lane = Ba + kq * AROW + l15;
+    const int nchunks = p.CinPad / KCG;
+    auto issue_x = [&](int c0) {
+        if (TAIL && c0 + KCG > p.Cin) xs.issue_tail(xbase + (int64_t)c0 * p.x_chan_stride, c0, p.Cin, p.x_chan_stride, tid);
+        else xs.issue(xbase + (int64_t)c0 * p.x_chan_stride);
+    };
+    ws.issue(wbase);
+    issue_x(0);
+    xs.commit(Xs);
+    issue_x(min(1, nchunks - 1) * KCG);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- P1: aggregate chunk c, commit its weights, load the next chunk's.  Per column the 8 x 6 (+ 8) source values are
+        // read first, all in flight together (the aggregated rows and the x rows share LDS: interleaved with the writes the
+        // reads would be issued six at a time, each batch behind the previous one's latency)
+        constexpr int KB = (CONVRES && NB > 20) ? 2 : 8;      // channels whose source values are in flight together (register budget)
+#pragma unroll
+        for (int n = 0; n < NCOL; ++n) {
+#pragma unroll
+            for (int k0 = 0; k0 < KCG; k0 += KB) {
+                float xv[KB][6], xi[KB];
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) {
+                    const float *bx = Xs + (k0 + kk) * XROW;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) xv[kk][e] = bx[eoff[n][e]];
+                    if (CONVRES) xi[kk] = bx[ioff[n]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) {
+                    const float b0 = eval[n][0] * xv[kk][0];
+                    const float b1 = eval[n][1] * xv[kk][1];
+                    float s2 = eval[n][2] * xv[kk][2];
+                    s2 = fmaf(eval[n][3], xv[kk][3], s2);
+                    s2 = fmaf(eval[n][4], xv[kk][4], s2);
+                    s2 = fmaf(eval[n][5], xv[kk][5], s2);
+                    Ba[gcn_entry(k0 + kk, 0, R) * AROW + acol[n]] = b0;
+                    Ba[gcn_entry(k0 + kk, 1, R) * AROW + acol[n]] = b1;
+                    Ba[gcn_entry(k0 + kk, 2, R) * AROW + acol[n]] = s2;
+                    if (CONVRES) Ba[gcn_entry(k0 + kk, 3, R) * AROW + acol[n]] = xi[kk];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        ws.commit(Wl);
+        ws.issue(wbase + (size_t)min(c + 1, nchunks - 1) * KCG * p.Mpad);
+        __syncthreads();
+        // ---- P2: x rows of chunk c + 1 -> LDS, chunk c + 2 -> registers, MFMAs of chunk c
+        xs.commit(Xs);
+        issue_x(min(c + 2, nchunks - 1) * KCG);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+    unsigned oslot[F], xslot[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        oslot[f] = (unsigned)((int64_t)f * p.y_seg_stride * 4);
+        xslot[f] = (unsigned)((int64_t)f * p.x_seg_stride * 4);
+    }
+    const int nrow = (int)min((int64_t)NPG, min(p.x_chan_stride, p.y_chan_stride) - q0) & ~3;
+    epilogue16<NB, F, NPG>(acc, p.bias, p.Cout, m0 + wave * 16 + l15, kq, !CONVRES, true, p.x + (int64_t)seg0 * p.x_seg_stride,
+                           p.y + (int64_t)seg0 * p.y_seg_stride, xslot, oslot, p.x_chan_stride, p.y_chan_stride, q0, nrow, nval);
+}
+
+template <int NB, int F>
+int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
+    constexpr int NT = 16 * NB, NPG = NT / F;
+    const int Q = p.frames * p.V;
+    p.qtiles = (unsigned)((Q + NPG - 1) / NPG); p.mtiles = (unsigned)(p.Mpad / 64);
+    const int64_t grid = (int64_t)p.qtiles * p.mtiles * (n_seg / F);
+    if (grid >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
+    const bool tail = (p.Cin % 8) != 0, conv = p.R == 4;
+    void (*kern)(GcnParams) = conv ? (tail ? gcn16_kernel<NB, F, true, true> : gcn16_kernel<NB, F, true, false>)
+                                   : (tail ? gcn16_kernel<NB, F, false, true> : gcn16_kernel<NB, F, false, false>);
+    const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 8 * NT) * sizeof(float);
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+template <int NB, int E, int HS>
+int launch16(StepParams p, int n_emit, hipStream_t s) {
+    typedef G16<NB, E, HS> G;
+    p.gx = (unsigned)((p.P + G::NP - 1) / G::NP); p.gy = (unsigned)(p.Mpad / 64); p.gz = (unsigned)(n_emit / E);
+    if ((int64_t)p.gx * p.gy * p.gz >= (1ll << 31)) CSK_FAIL("tcn_step: grid too large");
+    const bool tail = (p.C % G::KCH) != 0 || (p.res_mode == CSK_RES_CONV && (p.Cres % G::KR) != 0);
+    void (*kern)(StepParams) = tail ? tcn_step16_kernel<NB, E, HS, true> : tcn_step16_kernel<NB, E, HS, false>;
+    const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(p.gx * p.gy * p.gz), dim3(NTHREADS), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+// Time model of a launch: the chip is MFMA-bound, so a CU delivers the same work per unit time with one or two workgroups
+// resident; what counts is the largest number of tiles ONE CU has to run (tiles dealt evenly over the 256 CUs of an MI355X)
+// times the columns a 64-row tile carries (padding included).
+constexpr int64_t CUS = 256;
+inline double cost_model(int64_t tiles64, double tile_cols) { return (double)((tiles64 + CUS - 1) / CUS) * tile_cols; }
+
+}  // namespace
+
+// ---- dispatch ------------------------------------------------------------------------------------------------------------
+// CSK_STEP16 (under CSK_DIAG=1): 1 = never (the 32x32x2 kernels everywhere: A/B runs).
+// Temporal step: the K loop of this family walks (4-channel chunk, tap) where the 32x32x2 kernels walk (8-channel chunk, tap) --
+// a different fp32 summation order -- so WHICH family runs must not depend on the launch size (a stream's results must not
+// depend on how many streams share the slab, nor on how many frames a launch carries): every k = 9, unsplit launch whose
+// rings fit 32-bit byte offsets takes this family; only the tile WIDTH (NB) follows the launch shape.
+int csk_step16_enabled() { return csk_diag_int("CSK_STEP16") != 1; }
+
+int csk_launch_tcn_step16(StepParams p, int n_emit, void *stream) {
+    if (!csk_step16_enabled()) return -2;
+    if (p.K != 9 || p.ksplit != 1 || p.head_step < 1 || p.head_step > 2) return -2;
+    // 32-bit byte offsets inside the rings
+    const int64_t ring_bytes = (int64_t)p.slots * p.C * p.P * 4, xres_bytes = (int64_t)p.xres_slots * p.Cres * p.P * 4;
+    const int64_t out_bytes = (int64_t)p.out_slots * p.Cout * p.P * 4;
+    if (ring_bytes >= (1ll << 32) || xres_bytes >= (1ll << 32) || out_bytes >= (1ll << 32) || p.P < 8) return -2;
+    const int E = p.head_step == 2 ? (n_emit % 2 == 0 ? 2 : 1) : (n_emit % 4 == 0 ? 4 : n_emit % 2 == 0 ? 2 : 1);
+    const int HS = E > 1 ? p.head_step : 1;
+    const int64_t mt = p.Mpad / 64;
+    int best_nb = 0;
+    double best = 0;
+    for (int nb : {25, 18}) {
+        const int np = 16 * nb / E;
+        const double c = cost_model(((p.P + np - 1) / np) * mt * (n_emit / E), 16.0 * nb);
+        if (!best_nb || c < best) { best = c; best_nb = nb; }
+    }
+    hipStream_t s = (hipStream_t)stream;
+#define CSK_L16(NB_) (E == 4 ? launch16<NB_, 4, 1>(p, n_emit, s) : E == 2 ? (HS == 2 ? launch16<NB_, 2, 2>(p, n_emit, s) : launch16<NB_, 2, 1>(p, n_emit, s)) : launch16<NB_, 1, 1>(p, n_emit, s))
+    return best_nb == 25 ? CSK_L16(25) : CSK_L16(18);
+#undef CSK_L16
+}
+
+// Graph conv: bitwise the sums of gcn_stage_sparse2_kernel, so the choice IS a throughput policy of the launch shape: taken
+// where the cost model says the launch packs the chip better (CSK_GCN16=2 under CSK_DIAG=1: whenever the shape is supported).
+int csk_launch_gcn16(GcnParams p, int n_seg, void *stream) {
+    const int mode = csk_diag_int("CSK_GCN16");
+    if (!csk_step16_enabled() || mode == 1) return -2;
+    if (p.adj_seg_stride != 0 || p.ksplit != 1 || p.ell_cnt[0] > 1 || p.ell_cnt[1] > 1 || p.ell_cnt[2] > 4) return -2;
+    if ((p.x_seg_stride | p.x_chan_stride | p.y_seg_stride | p.y_chan_stride) & 3) return -2;
+    if (((uintptr_t)p.x | (uintptr_t)p.y) & 15) return -2;
+    const int F = n_seg % 4 == 0 ? 4 : n_seg % 2 == 0 ? 2 : 1;
+    if ((int64_t)F * p.x_seg_stride * 4 >= (1ll << 32) || (int64_t)F * p.y_seg_stride * 4 >= (1ll << 32)) return -2;
+    const int Q = p.frames * p.V;
+    const int64_t mt = p.Mpad / 64;
+    int best_nb = 0;
+    double best = 0;
+    for (int nb : {25, 18}) {
+        const int npg = 16 * nb / F;
+        if (npg % p.V) continue;                              // tiles hold whole skeletons
+        const double c = cost_model((int64_t)((Q + npg - 1) / npg) * mt * (n_seg / F), 16.0 * nb);
+        if (!best_nb || c < best) { best = c; best_nb = nb; }
+    }
+    if (!best_nb) return -2;
+    if (mode != 2) {
+        const bool big = (p.Mpad % 128) == 0;
+        const int nt32 = big ? 128 : 256;
+        const double c32 = cost_model((int64_t)((Q + nt32 - 1) / nt32) * (big ? p.Mpad / 128 : p.Mpad / 64) * n_seg, 256.0);
+        if (best >= 0.97 * c32) return -2;                   // not clearly better: keep the 32x32x2 tiles
+    }
+    hipStream_t s = (hipStream_t)stream;
+#define CSK_G16(NB_) (F == 4 ? launch_gcn16<NB_, 4>(p, n_seg, s) : F == 2 ? launch_gcn16<NB_, 2>(p, n_seg, s) : launch_gcn16<NB_, 1>(p, n_seg, s))
+    return best_nb == 25 ? CSK_G16(25) : CSK_G16(18);
+#undef CSK_G16
+}

@@ -252,8 +252,11 @@ def test_temporal_conv_split_k_entry_vs_oracle_and_unsplit(ci, co, stride, res, 
     m = m.to(DEV)
     plain = m(x.to(DEV)).cpu()
     from continual_skeletons_amd import blocks
-    blocks.split_scratch(torch.device(DEV), 1 << 22).fill_(float("nan"))
     m.clip_split_k = ksplit                                   # the temporal conv only (the graph conv has its own test)
+    # poison the partial-sum scratch AFTER sizing it for this launch (the block's own SplitScratch hands the same buffer
+    # back to the forward below): a partial sum that is read without having been written shows up as NaN
+    t_out = (T + 2 * 4 - 9) // stride + 1
+    blocks._scratch_of(m).get(torch.device(DEV), ksplit * N * co * t_out * 25).fill_(float("nan"))
     got = m(x.to(DEV)).cpu()
     check_parity(got, want, shape=(ci, co, stride, res, T, N, ksplit))
     check_parity(got, plain, note="split-K vs unsplit temporal conv (summation order)")

@@ -147,6 +147,69 @@ def test_config4_coagcn_1024_streams_kinetics_shape():
         assert torch.equal(gv[sel], sv)
 
 
+def _default_head_case(make_big, make_small, sd, V, classes, seed, oracle_gcn=None):
+    """1024 streams with the model-level DEFAULT head (models/base.py:84-101 -> AvgPool1d(75, stride 1, padding 19) over the
+    layer-10 features, what bench.py times): 304 frames = the first prediction (56th feature, frame 296) and one slide of the
+    75-entry window; 8 picked streams vs the oracle with the same 75 / 19 window, and stream invariance (bitwise) against a
+    4-stream slab stepped frame by frame."""
+    T = 304
+    frames = torch.rand((T, 1024, 3, V, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+    big = make_big().to(DEV)
+    assert (big.pool_size, big.pool_padding) == (75, 19)
+    got, t = [], 0
+    while t < T:
+        got += big.forward_cycle([frames[t + f] for f in range(4)])
+        t += 4
+    assert len(got) == 2 and all(gv.shape == (1024, classes) for gv in got)      # features 56 and 57 of 57
+    pick = [0, 3, 255, 256, 511, 640, 1000, 1023]
+    orc = o.CoStGcnOracle(sd, pool_size=75, pool_padding=19)
+    if oracle_gcn is not None:
+        for b in orc.blocks:
+            b.gcn = oracle_gcn
+    want = []
+    with torch.no_grad():
+        for t in range(T):
+            r = orc.forward_step(frames[t][pick].cpu())
+            if r is not None:
+                want.append(r)
+    assert len(want) == len(got)
+    for gv, wv in zip(got, want):
+        check_parity(gv[pick].cpu(), wv)
+    small = make_small(big).to(DEV)
+    sel = [3, 4, 640, 1023]
+    got_small = [r for r in (small.forward_step(frames[t][sel].contiguous()) for t in range(T)) if r is not None]
+    assert len(got_small) == len(got)
+    for gv, sv in zip(got, got_small):
+        assert torch.equal(gv[sel], sv)
+
+
+def test_config3_1024_streams_default_head():
+    a, sd, _ = g6_state_dict("ntu")
+
+    def make():
+        net = pkg.CoStGcn(A).eval()                 # pool_size / pool_padding left at their defaults
+        net.load_state_dict(sd, strict=True)
+        return net
+    _default_head_case(make, lambda big: make(), sd, 25, 60, 6)
+
+
+def test_config4_coagcn_1024_streams_default_head():
+    Ak = pkg.kinetics_graph().A
+
+    def make():
+        net = pkg.CoAGcn(Ak, input_shape=(3, 300, 18, 2), num_classes=400).eval()
+        _randomise_agcn(net, 23)
+        return net
+    big = make()
+    sd = {k.replace("0.1.", "").replace("0.0.residual", "residual"): v.clone() for k, v in big.state_dict().items()}
+
+    def make_small(b):
+        small = make()
+        small.load_state_dict(b.state_dict(), strict=True)       # make() draws fresh conv weights
+        return small
+    _default_head_case(lambda: big, make_small, sd, 18, 400, 7, oracle_gcn=o.adaptive_graph_conv)
+
+
 def test_config5_per_gpu_shard_of_1024_clips():
     """BASELINE configs[4] shards 8192 clips over 8 GPUs: one rank's 1024-clip shard in a single forward (3.9 GB
     activations per 64-channel layer) must reproduce, bit for bit, the same clips run 256 at a time, which is what

@@ -145,6 +145,31 @@ def test_bench_self_launch_two_ranks_toy_sizes():
     assert len(d["per_rank"]) == 2 and 0 < d["roofline_config"]["frac"] < 1 and d["roofline_config"]["n_gpus"] == 2
 
 
+def test_bench_self_launch_eight_ranks_toy_sizes():
+    """The rank count of BASELINE configs[4]: `python bench.py --gpus 8` (self-launch, gloo, the eight ranks SHARE the one GPU
+    of this box) must produce ONE line with eight `per_rank` rows, whole-job fractions priced against 8 x one GPU's peak
+    (0 < frac < 1) and the configs[4] leg over 8 shards.  The RCCL exchange over xGMI itself can only run on the driver's
+    8-GPU node (README: no scaling curve has been measured)."""
+    env = dict(os.environ, CSK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "2", "--streams", "4", "--steps", "2",
+           "--warmup", "1", "--step-cycles", "2", "--stream-shards", "1", "--no-cpu-baseline", "--config5-batch", "2",
+           "--no-split-leg"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert d["config5"]["clips_per_gpu"] == 2 and d["config5"]["global_batch"] == 16 and d["config5"]["value"] > 0
+    assert d["ranks_seen"] == 1 and d["collective_backend"] == "gloo" and d["value"] > 0
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8)) and all(r["ms_per_step"] > 0 and r["device_uuid"] for r in pr)
+    for rc in (d["roofline_config"], d["config5"]["roofline_config"], d["costgcn_online"]["roofline_config"]):
+        assert rc["n_gpus"] == 8 and 0 < rc["frac"] < 1 and 0 < rc["frac_alg"] < 1, rc
+
+
 RCCL_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["CSK_ROOT"])

@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests of the batch-shard + logit all-gather path (runs on CPU)."""
+"""world_size-2 and world_size-8 gloo tests of the batch-shard + logit all-gather path (runs on CPU)."""
 import os
 import socket
 
@@ -30,16 +30,20 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-def _run(n_total):
+def _run(n_total, world=2):
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(60)
-    assert res == {0: True, 1: True}
+    try:
+        res = dict(q.get(timeout=300) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()                                  # the exact processes this test started
+    assert res == {r: True for r in range(world)}
 
 
 def test_shard_bounds_cover_and_partition():
@@ -57,6 +61,18 @@ def test_all_gather_even_world2():
 
 def test_all_gather_ragged_world2():
     _run(7)
+
+
+def test_all_gather_even_world8():
+    """BASELINE configs[4] has 8 ranks: the rank-major order of the gathered logits at world size 8 (64 clips, 8 per rank;
+    the 8-GPU node itself is the driver's to run)."""
+    _run(64, world=8)
+
+
+def test_all_gather_ragged_world8():
+    """Uneven shards at 8 ranks: 61 clips -> five ranks of 8 and three of 7 (shard_bounds), and fewer clips than ranks (5)."""
+    _run(61, world=8)
+    _run(5, world=8)
 
 
 def test_bench_self_launches_its_ranks_without_a_gpu_call_in_the_parent():

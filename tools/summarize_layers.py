@@ -23,7 +23,7 @@ import workmodel as wm  # noqa: E402
 
 
 def short(name):
-    for k in ("gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
+    for k in ("tcn_step16_kernel", "gcn16_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
               "input_norm_frames_kernel", "co_head_kernel", "gcn_reduce_kernel", "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
               "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel", "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "gcn_stage_dense_kernel", "gcn_stage_dense2_kernel"):
         if k in name:
@@ -35,7 +35,7 @@ def short(name):
 def klass(name):
     if "agcn_" in name:
         return "a"
-    if "gcn_stage" in name or "gcn_split" in name:
+    if "gcn_stage" in name or "gcn_split" in name or "gcn16" in name:
         return "g"
     if "tcn_step" in name or "tcn_stage" in name or "tcn_split" in name:
         return "t"
