@@ -135,6 +135,12 @@ extern "C" void csk_co_plan_reset(csk_co_plan *plan) {
     plan->frames = plan->feats = 0;
 }
 
+// a whole emitting 4-frame cycle of a 64-row block that csk_co_block_step_f32 / csk_co_stack_step_f32 take (continual.py:_fusable)
+static bool fusable_cycle(const csk_co_layer &l, const BlockCounters &c, int r, int V) {
+    return l.agcn_inter == 0 && r == 4 && l.stride == 1 && l.c_out <= 64 && c.s >= 4 && l.res_kind != CSK_RES_CONV && l.tcn_ksplit <= 1 &&
+           l.gcn_ksplit <= 1 && l.ell_cnt[0] <= 1 && l.ell_cnt[1] <= 1 && l.ell_cnt[2] <= 4 && ((64 + V - 2) / V + 1) * V <= 128;
+}
+
 // one block: r frames are already in xin[(s .. s+r-1) % HIST] (HIST = depth of the input ring = the upstream layer's
 // out_slots); returns emissions via *slot0 / *n_emit
 static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *xin, int HIST, int r, int n_frames, int V,
@@ -145,9 +151,7 @@ static int advance_block(const csk_co_layer &l, BlockCounters &c, const float *x
     if (r + K - 1 > YRING || r + LAG > HIST)
         CSK_FAIL("co_plan_cycle: %d frames do not fit the rings of a layer (y ring %d slots, input ring %d)", r, YRING, HIST);
     // one fused launch for a whole emitting 4-frame cycle of a 64-row block (continual.py:_fusable)
-    if (fuse && l.agcn_inter == 0 && r == 4 && l.stride == 1 && l.c_out <= 64 && s0 >= DELAY && l.res_kind != CSK_RES_CONV && l.tcn_ksplit <= 1 &&
-        l.gcn_ksplit <= 1 &&
-        l.ell_cnt[0] <= 1 && l.ell_cnt[1] <= 1 && l.ell_cnt[2] <= 4 && ((64 + V - 2) / V + 1) * V <= 128) {
+    if (fuse && fusable_cycle(l, c, r, V)) {
         *slot0 = (int)(c.e % OUT);
         const int rc = csk_co_block_step_f32(xin, HIST, (int)(s0 % HIST), l.c_in, l.gcn_w, l.gcn_bias,
                                          l.ell_src, l.ell_val, l.ell_cnt, l.ell_w, l.gcn_res_mode, l.y_ring, YRING,
@@ -218,6 +222,35 @@ static int run_blocks(csk_co_plan *p, int r, int *slot0, int *n_last, void *stre
     int rr = r, in_slots = p->xin0_slots;
     *n_last = 0;
     for (size_t i = 0; i < p->layers.size(); ++i) {
+        // consecutive blocks that each advance a whole emitting cycle: ONE launch for the run (csk_co_stack_step_f32)
+        auto stackable = [&](size_t k, int r) {             // identity gcn_residual: what the fused stack kernel covers
+            return fusable_cycle(p->layers[k], p->cnt[k], r, p->V) && p->layers[k].gcn_res_mode == CSK_RES_IDENTITY;
+        };
+        if (p->fuse && i + 1 < p->layers.size() && stackable(i, rr) && stackable(i + 1, 4)) {
+            csk_co_block_args args[CSK_CO_STACK_MAX];
+            int n = 0;
+            size_t j = i;
+            for (; j < p->layers.size() && n < CSK_CO_STACK_MAX && stackable(j, 4); ++j, ++n) {
+                const csk_co_layer &l = p->layers[j];
+                const long s0 = p->cnt[j].s;
+                if (4 + 8 > l.y_slots || 4 + 4 > in_slots) CSK_FAIL("co_plan_cycle: 4 frames do not fit the rings of layer %d", (int)j);
+                csk_co_block_args &a = args[n];
+                a.xin = xin; a.xin_slots = in_slots; a.xin_slot0 = (int)(s0 % in_slots); a.c_in = l.c_in; a.gcn_w = l.gcn_w;
+                a.gcn_bias = l.gcn_bias; a.ell_src = l.ell_src; a.ell_val = l.ell_val;
+                a.ell_cnt[0] = l.ell_cnt[0]; a.ell_cnt[1] = l.ell_cnt[1]; a.ell_cnt[2] = l.ell_cnt[2];
+                a.ell_w = l.ell_w; a.gcn_res_mode = l.gcn_res_mode; a.y_ring = l.y_ring; a.y_slots = l.y_slots; a.y_slot0 = (int)(s0 % l.y_slots);
+                a.tcn_w = l.tcn_w; a.tcn_bias = l.tcn_bias; a.res_mode = l.res_kind; a.x_res_slot0 = (int)((s0 - 4) % in_slots);
+                a.out = l.out_ring; a.out_slots = l.out_slots; a.out_slot0 = (int)(p->cnt[j].e % l.out_slots); a.c_out = l.c_out;
+                xin = l.out_ring;
+                in_slots = l.out_slots;
+            }
+            if (const int rc = csk_co_stack_step_f32(n, args, p->N * p->M, p->V, p->P, stream)) return rc;
+            for (size_t k = i; k < j; ++k) { p->cnt[k].s += 4; p->cnt[k].e += 4; }
+            *slot0 = args[n - 1].out_slot0;
+            rr = 4;
+            i = j - 1;
+            continue;
+        }
         int ne = 0;
         const int rc = advance_block(p->layers[i], p->cnt[i], xin, in_slots, rr, p->N * p->M, p->V, p->P, slot0, &ne, p->fuse, stream);
         if (rc) return rc;

@@ -22,6 +22,9 @@ struct GcnParams {
     // partial sums to part[(seg * ksplit + ks)][Cout][y_chan_stride]; gcn_reduce_kernel adds them up in split order
     int ksplit, cper;
     float *part;
+    // step16.hip: segment s of the launch is slot (ring_slot0 + s) % ring_slots of x / y (plain calls: no wrap, 1 << 30 slots)
+    int x_ring_slots, x_ring_slot0, y_ring_slots, y_ring_slot0;
+    int stagger;         // step16.hip: start delay of the odd-slot workgroup of a CU, x 64 cycles
 };
 
 // gcn_dense.hip: dense (per-segment or per-frame) adjacency with an even joint count V <= 18; returns -2 when the shape is

@@ -613,6 +613,7 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     }
     if (((uintptr_t)ring | (uintptr_t)(x_res ? x_res : ring)) & 15) CSK_FAIL("tcn_step: state pointers must be 16-byte aligned");
     StepParams p;
+    p.stagger = 0;
     p.ring = ring; p.w = w; p.xres = x_res ? x_res : ring; p.wres = w_res; p.bias = bias; p.out = out;
     p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.K = k; p.slots = slots; p.head = head; p.head_step = head_step; p.res_mode = res_mode;
@@ -714,9 +715,18 @@ extern "C" int csk_co_block_step_f32(const float *xin, int xin_slots, int xin_sl
     p.V = V; p.n_skel = n_skel; p.vmagic = vmagic_of(V); p.fast_epi_g = t.fast_epi;
     p.ldbx = round_up(((NP + V - 2) / V + 1) * V, 4);
     if (p.ldbx > 128) CSK_FAIL("co_block_step: %d joints per skeleton make the input strip of a 64-position tile longer than 128", V);
-    // With the slot-balanced tile family (step16.hip) the cycle is its two launches: the family's temporal step has its own
-    // fp32 summation order, and a block must give the same bits whether its frames arrive one by one or four at a time
+    // With the slot-balanced tile family (step16.hip) the cycle is that family's fused launch or its two launches: the family's
+    // temporal step has its own fp32 summation order, and a block must give the same bits whether its frames arrive one by one
+    // or four at a time
     if (csk_step16_enabled()) {
+        csk_co_block_args a;
+        a.xin = xin; a.xin_slots = xin_slots; a.xin_slot0 = xin_slot0; a.c_in = c_in; a.gcn_w = gcn_w; a.gcn_bias = gcn_bias;
+        a.ell_src = ell_src; a.ell_val = ell_val; a.ell_cnt[0] = ell_cnt[0]; a.ell_cnt[1] = ell_cnt[1]; a.ell_cnt[2] = ell_cnt[2];
+        a.ell_w = ell_w; a.gcn_res_mode = gcn_res_mode; a.y_ring = y_ring; a.y_slots = y_slots; a.y_slot0 = y_slot0; a.tcn_w = tcn_w;
+        a.tcn_bias = tcn_bias; a.res_mode = res_mode; a.x_res_slot0 = x_res_slot0; a.out = out; a.out_slots = out_slots;
+        a.out_slot0 = out_slot0; a.c_out = c_out;
+        const int rc1 = csk_launch_co_stack16(1, &a, n_skel, V, P, stream);      // one launch where the tile family covers the shape
+        if (rc1 != -2) return rc1;
         for (int f = 0; f < 4;) {                              // one graph-conv launch per non-wrapping slot run
             const int xs = (xin_slot0 + f) % xin_slots, ys = (y_slot0 + f) % y_slots;
             int run = 4 - f;

@@ -28,6 +28,19 @@
 
 namespace {
 
+// Time model of a launch: the chip is MFMA-bound, so a CU delivers the same work per unit time with one or two workgroups
+// resident; what counts is the largest number of tiles ONE CU has to run (tiles dealt evenly over the 256 CUs of an MI355X)
+// times the columns a 64-row tile carries (padding included).
+constexpr int64_t CUS = 256;
+// start stagger of the odd-slot workgroup in units of 64 cycles (stagger_odd_slot); CSK_*_STAGGER under CSK_DIAG=1 overrides
+// (value + 1: 1 = off)
+constexpr int GCN16_STAGGER = 64, TCN16_STAGGER = 0;
+inline int stagger_units(const char *env, int dflt) {
+    const int v = csk_diag_int(env);
+    return v > 0 ? v - 1 : dflt;
+}
+inline double cost_model(int64_t tiles64, double tile_cols) { return (double)((tiles64 + CUS - 1) / CUS) * tile_cols; }
+
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 constexpr int row16(int n) { return ((n - 16 + 31) / 32) * 32 + 16; }   // smallest stride >= n that is 16 (mod 32)
 
@@ -50,22 +63,26 @@ struct G16 {
 
 // Staging of KCHX channel rows x NSL ring slots x NP positions (register prefetch: issue = global -> registers, commit =
 // registers -> LDS).  Unit e of the (channel, slot, quad) space, quad fastest; a thread owns units sweep * 256 + tid.
-template <int KCHX, int NSL, int NP, int ROWX, bool EVENODD>
+template <int KCHX, int NSL, int NP, int ROWX, bool EVENODD, bool PARTIAL = false>
 struct Win16 {
     static constexpr int Q = NP / 4, U = KCHX * NSL * Q, NSW = (U + NTHREADS - 1) / NTHREADS, NEV = (NSL + 1) / 2;
     static_assert(KCHX * ROWX * 4 < 65536, "LDS byte offsets are packed two to a register");
     unsigned goff[NSW];            // byte offset from (ring + c0 * P + p0): the ring is < 4 GB (checked by the launcher)
     unsigned loff2[(NSW + 1) / 2]; // LDS byte offsets of sweeps 2 i (low half) and 2 i + 1 (high half)
+    unsigned gback[PARTIAL ? NSW : 1];   // PARTIAL: bytes to step back in the chunk that holds only `nreal` real channel rows (rows
+                                         // past them re-read the last real row: their weights are zero, the value only has to be finite)
     f32x4 v[NSW];
     // slot w of the window = slot (first + w * step) % slots of the source (slot_stride floats apart, channel rows chan_stride
     // apart); pmax = last legal f32x4 start relative to the tile's first position
-    __device__ __forceinline__ void setup(int first, int step, int slots, int64_t slot_stride, int64_t chan_stride, int pmax, int tid) {
+    __device__ __forceinline__ void setup(int first, int step, int slots, int64_t slot_stride, int64_t chan_stride, int pmax, int tid,
+                                          int nreal = KCHX) {
 #pragma unroll
         for (int u = 0; u < NSW; ++u) {
             const int e = min(u * NTHREADS + tid, U - 1);
             const int i = e % Q, rw = e / Q, w = rw % NSL, kk = rw / NSL;
             const int64_t so = (int64_t)((first + w * step) % slots) * slot_stride + (int64_t)kk * chan_stride + min(4 * i, pmax);
             goff[u] = (unsigned)(so * 4);
+            if (PARTIAL) gback[u] = (unsigned)((int64_t)max(kk - (nreal - 1), 0) * chan_stride * 4);
             const int sl = EVENODD ? ((w & 1) ? (NEV + (w >> 1)) * NP : (w >> 1) * NP) : w * NP;
             const unsigned lo = (unsigned)(kk * ROWX + sl + 4 * i) * 4u;
             if (u & 1) loff2[u / 2] |= lo << 16;
@@ -86,6 +103,15 @@ struct Win16 {
     template <int G>
     __device__ __forceinline__ void issue_third(const float *__restrict__ base) { issue_range<G * NSW / 3, (G + 1) * NSW / 3>(base); }
     __device__ __forceinline__ void issue(const float *__restrict__ base) { issue_range<0, NSW>(base); }
+    // PARTIAL: `partial` (wave-uniform) picks the clamped offsets
+    __device__ __forceinline__ void issue_sel(const float *__restrict__ base, bool partial) {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            unsigned g = goff[u] - (partial ? gback[PARTIAL ? u : 0] : 0u);
+            asm volatile("" : "+v"(g));
+            v[u] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + g);
+        }
+    }
     // chunk whose channels c0 .. c0 + KCHX - 1 reach past C: rows >= C are read from row C - 1 and zeroed (their weights are
     // zero as well; the product must not be 0 x Inf)
     __device__ __forceinline__ void issue_tail(const float *__restrict__ base, int c0, int C, int64_t chan_stride, int tid) {
@@ -140,6 +166,15 @@ struct W16 {
         for (int u = 0; u < NSW; ++u) *reinterpret_cast<f32x4 *>(Wl + loff[u]) = v[u];
     }
 };
+
+// The two workgroups of a CU start together and do identical work: left alone they run in LOCKSTEP -- both in their
+// matrix-free phase (graph conv: aggregation; temporal step: commit + barriers) at the same time, the matrix pipe idle, then
+// both contending for it.  The workgroup in the odd wave slot of its SIMDs (HW_ID.wave_id) therefore starts `units` x 64
+// cycles late: one phase behind its partner, where it stays (matrix beside memory).  Speed only, never correctness.
+__device__ __forceinline__ void stagger_odd_slot(int units) {
+    if (units > 0 && (__builtin_amdgcn_s_getreg(6148) & 1))                     // HW_REG_HW_ID bits [3:0]: wave slot on the SIMD
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(1);
+}
 
 // one tap (one k-step of 4 channels): acc[cb] += act[16 cb .. + 15][k] x w[k][16 channels]
 template <int NB>
@@ -218,16 +253,14 @@ __device__ __forceinline__ void epilogue16(f32x4 (&acc)[NB], const float *__rest
 // TAIL: channel counts that are not whole chunks (C % 4, C_res % 8): the chunk that reaches past C is staged with clamped,
 // zeroed rows (uniform branches in the K loop); the fast instantiation has none.
 template <int NB, int E, int HS, bool TAIL>
-__global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(const StepParams p) {
+__device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, const int by, const int bz, float *smem) {
     typedef G16<NB, E, HS> G;
     constexpr int KCH = G::KCH, NP = G::NP, ROW = G::ROW, LDW = G::LDW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem, *Bl = smem + G::WSZ;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));      // opaque: inside a fused stack the per-thread setup must not be hoisted out of the block loop (and spilled)
+    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    // XCD-contiguous work order, m-tile fastest (the m-tiles of a position tile read the same ring window)
-    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int by = (int)(wid % p.gy), bz = (int)((wid / p.gy) % p.gz), bx = (int)(wid / (p.gy * p.gz));
     const int m0 = by * 64, p0 = bx * NP, j0 = bz * E;
     const int64_t P = p.P;
     int first = (p.head + j0 * p.head_step - 8) % p.slots;                     // ring slot of window slot 0
@@ -322,6 +355,15 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(cons
                           xslot, oslot, P, P, p0, nval, nval);
 }
 
+template <int NB, int E, int HS, bool TAIL>
+__global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(const StepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stagger_odd_slot(p.stagger);
+    // XCD-contiguous work order, m-tile fastest (the m-tiles of a position tile read the same ring window)
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    tcn16_tile<NB, E, HS, TAIL>(p, (int)(wid / (p.gy * p.gz)), (int)(wid % p.gy), (int)((wid / p.gy) % p.gz), smem);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Graph conv on the same tiles (csk_gcn_stage_f32 for skeleton-sparse adjacencies, <= 1 / 1 / 4 non-zeros per column):
 //     y[f][co][q] = ReLU( sum_r sum_c W_r[c][co] * agg_r(x_f)[c][q] + bias[co] + gcn_residual )
@@ -333,18 +375,21 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(cons
 //   P2  the MFMAs walk the rows four at a time (the chain of the 32x32x2 kernel's k-step pairs: bitwise the same sums); the
 //       next chunk's x rows are committed and the one after is loaded underneath.
 // Two barriers per chunk, x single-buffered (read in P1, rewritten in P2).
-template <int NB, int F, bool CONVRES, bool TAIL>
-__global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void gcn16_kernel(const GcnParams p) {
+// Segment f of a group is slot (ring_slot0 + seg0 + f) % ring_slots of x / y (a plain csk_gcn_stage_f32 call: no wrap).  A channel
+// count that is not a multiple of 8: the chunk holding the last real channels re-reads the last real row for the rows past it,
+// chunks of padding only re-read that chunk (their packed weights are zero; the value only has to be finite -- the clamp of
+// gcn_stage_sparse2_kernel).
+template <int NB, int F, bool CONVRES>
+__device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, const int qt, const int sg, float *smem) {
     constexpr int R = CONVRES ? 4 : 3, KCG = 8, NE = KCG * R;
     constexpr int NT = 16 * NB, NPG = NT / F, AROW = row16(NT), XROW = NT, LDW = 80;
     constexpr int NCOL = (NT + NTHREADS - 1) / NTHREADS;               // columns aggregated per thread
     static_assert(NT % F == 0 && NPG % 4 == 0, "a segment's positions are whole 16-byte quads");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem, *Ba = smem + NE * LDW, *Xs = Ba + NE * AROW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));      // opaque: inside a fused stack the per-thread setup must not be hoisted out of the block loop (and spilled)
+    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int mt = (int)(wid % p.mtiles), qt = (int)((wid / p.mtiles) % p.qtiles), sg = (int)(wid / (p.mtiles * p.qtiles));
     const int m0 = mt * 64, q0 = qt * NPG, seg0 = sg * F;
     const int V = p.V, Q = p.frames * V;
     const int nval = min(NPG, Q - q0);                                 // valid positions of the tile: whole skeletons
@@ -372,22 +417,25 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void gcn16_kernel(const Gcn
     for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     W16<R, KCG, LDW, true> ws;
-    Win16<KCG, F, NPG, XROW, false> xs;
+    Win16<KCG, F, NPG, XROW, false, true> xs;
+    const int nfull = p.Cin / KCG, rem = p.Cin % KCG;                  // whole chunks, real channels of the partial one
+    const int clast = rem ? nfull : nfull - 1;                         // last chunk with a real channel
     ws.setup(p.CinPad, p.Mpad, tid);
-    xs.setup(0, 1, 1 << 30, p.x_seg_stride, p.x_chan_stride, (int)(p.x_chan_stride - 4 - q0), tid);
+    xs.setup(p.x_ring_slot0 + seg0, 1, p.x_ring_slots, p.x_seg_stride, p.x_chan_stride, (int)(p.x_chan_stride - 4 - q0), tid, rem ? rem : KCG);
     const float *wbase = p.w + m0;
-    const float *xbase = p.x + (int64_t)seg0 * p.x_seg_stride + q0;
+    const float *xbase = p.x + q0;
     const float *wl_lane = Wl + kq * LDW + wave * 16 + l15;
     const float *ba_lane = Ba + kq * AROW + l15;
     const int nchunks = p.CinPad / KCG;
-    auto issue_x = [&](int c0) {
-        if (TAIL && c0 + KCG > p.Cin) xs.issue_tail(xbase + (int64_t)c0 * p.x_chan_stride, c0, p.Cin, p.x_chan_stride, tid);
-        else xs.issue(xbase + (int64_t)c0 * p.x_chan_stride);
+    auto issue_x = [&](int c) {                                        // chunk c of the K loop
+        const int cc = min(c, clast);
+        xs.issue_sel(xbase + (int64_t)cc * KCG * p.x_chan_stride, rem != 0 && cc == nfull);
     };
     ws.issue(wbase);
     issue_x(0);
+    __syncthreads();                                                   // (a previous phase of a fused launch may still read LDS)
     xs.commit(Xs);
-    issue_x(min(1, nchunks - 1) * KCG);
+    issue_x(1);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         // ---- P1: aggregate chunk c, commit its weights, load the next chunk's.  Per column the 8 x 6 (+ 8) source values are
@@ -398,13 +446,12 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void gcn16_kernel(const Gcn
         for (int n = 0; n < NCOL; ++n) {
 #pragma unroll
             for (int k0 = 0; k0 < KCG; k0 += KB) {
-                float xv[KB][6], xi[KB];
+                float xv[KB][6];
 #pragma unroll
                 for (int kk = 0; kk < KB; ++kk) {
                     const float *bx = Xs + (k0 + kk) * XROW;
 #pragma unroll
                     for (int e = 0; e < 6; ++e) xv[kk][e] = bx[eoff[n][e]];
-                    if (CONVRES) xi[kk] = bx[ioff[n]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -418,8 +465,15 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void gcn16_kernel(const Gcn
                     Ba[gcn_entry(k0 + kk, 0, R) * AROW + acol[n]] = b0;
                     Ba[gcn_entry(k0 + kk, 1, R) * AROW + acol[n]] = b1;
                     Ba[gcn_entry(k0 + kk, 2, R) * AROW + acol[n]] = s2;
-                    if (CONVRES) Ba[gcn_entry(k0 + kk, 3, R) * AROW + acol[n]] = xi[kk];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (CONVRES) {                                    // fourth "subset": the input itself (the conv gcn_residual's operand)
+                float xi[KCG];
+#pragma unroll
+                for (int kk = 0; kk < KCG; ++kk) xi[kk] = Xs[kk * XROW + ioff[n]];
+#pragma unroll
+                for (int kk = 0; kk < KCG; ++kk) Ba[gcn_entry(kk, 3, R) * AROW + acol[n]] = xi[kk];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -428,7 +482,7 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void gcn16_kernel(const Gcn
         __syncthreads();
         // ---- P2: x rows of chunk c + 1 -> LDS, chunk c + 2 -> registers, MFMAs of chunk c
         xs.commit(Xs);
-        issue_x(min(c + 2, nchunks - 1) * KCG);
+        issue_x(c + 2);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
@@ -438,13 +492,64 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void gcn16_kernel(const Gcn
     unsigned oslot[F], xslot[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        oslot[f] = (unsigned)((int64_t)f * p.y_seg_stride * 4);
-        xslot[f] = (unsigned)((int64_t)f * p.x_seg_stride * 4);
+        oslot[f] = (unsigned)((int64_t)((p.y_ring_slot0 + seg0 + f) % p.y_ring_slots) * p.y_seg_stride * 4);
+        xslot[f] = (unsigned)((int64_t)((p.x_ring_slot0 + seg0 + f) % p.x_ring_slots) * p.x_seg_stride * 4);
     }
     const int nrow = (int)min((int64_t)NPG, min(p.x_chan_stride, p.y_chan_stride) - q0) & ~3;
-    epilogue16<NB, F, NPG>(acc, p.bias, p.Cout, m0 + wave * 16 + l15, kq, !CONVRES, true, p.x + (int64_t)seg0 * p.x_seg_stride,
-                           p.y + (int64_t)seg0 * p.y_seg_stride, xslot, oslot, p.x_chan_stride, p.y_chan_stride, q0, nrow, nval);
+    // (lane coordinates recomputed from an opaque thread id: kept live across the K loop they would be the registers that spill
+    // in the 256-register conv-residual instantiation)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    epilogue16<NB, F, NPG>(acc, p.bias, p.Cout, m0 + __builtin_amdgcn_readfirstlane(tid2 >> 6) * 16 + (tid2 & 15), (tid2 & 63) >> 4, !CONVRES, true,
+                           p.x, p.y, xslot, oslot, p.x_chan_stride, p.y_chan_stride, q0, nrow, nval);
 }
+
+template <int NB, int F, bool CONVRES>
+__global__ __launch_bounds__(NTHREADS, 2) void gcn16_kernel(const GcnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stagger_odd_slot(p.stagger);
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    gcn16_tile<NB, F, CONVRES>(p, (int)(wid % p.mtiles), (int)((wid / p.mtiles) % p.qtiles), (int)(wid / (p.mtiles * p.qtiles)), smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A stack of 64-channel continual blocks in ONE launch (csk_co_stack_step_f32): the workgroup that owns NP positions of the
+// four new frames carries them through graph conv and temporal step of block 1, 2, ... -- every dependency of a tile is on
+// the SAME tile of the stage before (step mode has no temporal halo and a tile holds whole skeletons), so no workgroup ever
+// waits for another.  A stage's output reaches the next stage through the state rings (it is state: later cycles need it)
+// and L2: stores retired, workgroup barrier, L1 invalidated.  Same tile functions as the stand-alone launches: bitwise the
+// same results; what the stack saves is launches with their fill / drain and the co-resident workgroups of a CU drifting
+// apart into different phases (matrix beside memory instead of matrix beside matrix).
+// ------------------------------------------------------------------------------------------------
+struct CoStackBlock {
+    GcnParams g;
+    StepParams t;
+};
+struct CoStackParams {
+    CoStackBlock b[CSK_CO_STACK_MAX];
+    int nblk;
+};
+
+__device__ __forceinline__ void stage_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // this wave's stores have retired
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // drop L1 lines that were pulled before the stores
+}
+
+template <int NB>
+__global__ __launch_bounds__(NTHREADS, 2) void co_stack16_kernel(const CoStackParams sp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stagger_odd_slot(sp.b[0].g.stagger);
+    const int bx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+    for (int i = 0; i < sp.nblk; ++i) {
+        const CoStackBlock &b = sp.b[i];
+        gcn16_tile<NB, 4, false>(b.g, 0, bx, 0, smem);         // identity gcn_residual only (c_in == c_out): see csk_launch_co_stack16
+        stage_handoff();
+        tcn16_tile<NB, 4, 1, false>(b.t, bx, 0, 0, smem);
+        if (i + 1 < sp.nblk) stage_handoff();
+    }
+}
+
 
 template <int NB, int F>
 int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
@@ -453,9 +558,8 @@ int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
     p.qtiles = (unsigned)((Q + NPG - 1) / NPG); p.mtiles = (unsigned)(p.Mpad / 64);
     const int64_t grid = (int64_t)p.qtiles * p.mtiles * (n_seg / F);
     if (grid >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
-    const bool tail = (p.Cin % 8) != 0, conv = p.R == 4;
-    void (*kern)(GcnParams) = conv ? (tail ? gcn16_kernel<NB, F, true, true> : gcn16_kernel<NB, F, true, false>)
-                                   : (tail ? gcn16_kernel<NB, F, false, true> : gcn16_kernel<NB, F, false, false>);
+    void (*kern)(GcnParams) = p.R == 4 ? gcn16_kernel<NB, F, true> : gcn16_kernel<NB, F, false>;
+    p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER);
     const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 8 * NT) * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, p);
@@ -468,18 +572,13 @@ int launch16(StepParams p, int n_emit, hipStream_t s) {
     p.gx = (unsigned)((p.P + G::NP - 1) / G::NP); p.gy = (unsigned)(p.Mpad / 64); p.gz = (unsigned)(n_emit / E);
     if ((int64_t)p.gx * p.gy * p.gz >= (1ll << 31)) CSK_FAIL("tcn_step: grid too large");
     const bool tail = (p.C % G::KCH) != 0 || (p.res_mode == CSK_RES_CONV && (p.Cres % G::KR) != 0);
+    p.stagger = stagger_units("CSK_TCN16_STAGGER", TCN16_STAGGER);
     void (*kern)(StepParams) = tail ? tcn_step16_kernel<NB, E, HS, true> : tcn_step16_kernel<NB, E, HS, false>;
     const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, dim3(p.gx * p.gy * p.gz), dim3(NTHREADS), lds, s, p);
     return (int)hipGetLastError();
 }
-
-// Time model of a launch: the chip is MFMA-bound, so a CU delivers the same work per unit time with one or two workgroups
-// resident; what counts is the largest number of tiles ONE CU has to run (tiles dealt evenly over the 256 CUs of an MI355X)
-// times the columns a 64-row tile carries (padding included).
-constexpr int64_t CUS = 256;
-inline double cost_model(int64_t tiles64, double tile_cols) { return (double)((tiles64 + CUS - 1) / CUS) * tile_cols; }
 
 }  // namespace
 
@@ -545,4 +644,93 @@ int csk_launch_gcn16(GcnParams p, int n_seg, void *stream) {
 #define CSK_G16(NB_) (F == 4 ? launch_gcn16<NB_, 4>(p, n_seg, s) : F == 2 ? launch_gcn16<NB_, 2>(p, n_seg, s) : launch_gcn16<NB_, 1>(p, n_seg, s))
     return best_nb == 25 ? CSK_G16(25) : CSK_G16(18);
 #undef CSK_G16
+}
+
+// ---- stack of 64-channel blocks ------------------------------------------------------------------------------------------
+// -2: not a shape the fused stack is built for (the caller issues the per-stage launches); CSK_STACK16=1 under CSK_DIAG=1: never
+int csk_launch_co_stack16(int n_blocks, const csk_co_block_args *b, int n_skel, int V, int64_t P, void *stream) {
+    if (!csk_step16_enabled() || csk_diag_int("CSK_STACK16") == 1) return -2;
+    if (n_blocks < 1 || n_blocks > CSK_CO_STACK_MAX || P < 8 || (P & 3)) return -2;
+    const int64_t Q = (int64_t)n_skel * V;
+    int best_nb = 0;
+    double best = 0;
+    for (int nb : {25, 18}) {
+        const int np = 16 * nb / 4;
+        if (np % V) continue;                                 // tiles hold whole skeletons
+        const double c = cost_model((P + np - 1) / np, 16.0 * nb);
+        if (!best_nb || c < best) { best = c; best_nb = nb; }
+    }
+    if (!best_nb) return -2;
+    const int NP = 16 * best_nb / 4;
+    CoStackParams sp;
+    sp.nblk = n_blocks;
+    for (int i = 0; i < n_blocks; ++i) {
+        const csk_co_block_args &a = b[i];
+        if (a.c_out > 64 || (a.c_out & 3) || a.ell_cnt[0] > 1 || a.ell_cnt[1] > 1 || a.ell_cnt[2] > 4) return -2;
+        // a conv gcn_residual (c_in != c_out: the first block of a network) has a fourth operand subset and with it the register
+        // budget of a kernel of its own: such a block runs as its two launches
+        if (a.gcn_res_mode != CSK_RES_IDENTITY) return -2;
+        if ((int64_t)a.xin_slots * a.c_in * P * 4 >= (1ll << 32) || (int64_t)a.y_slots * a.c_out * P * 4 >= (1ll << 32) ||
+            (int64_t)a.out_slots * a.c_out * P * 4 >= (1ll << 32))
+            return -2;
+        GcnParams &g = sp.b[i].g;
+        g = GcnParams{};
+        g.x = a.xin; g.w = a.gcn_w; g.bias = a.gcn_bias; g.y = a.y_ring; g.ell_src = a.ell_src; g.ell_val = a.ell_val;
+        for (int k = 0; k < 3; ++k) g.ell_cnt[k] = a.ell_cnt[k];
+        g.ell_w = a.ell_w; g.adj_seg_stride = 0;
+        g.x_seg_stride = (int64_t)a.c_in * P; g.x_chan_stride = P; g.y_seg_stride = (int64_t)a.c_out * P; g.y_chan_stride = P;
+        g.Cin = a.c_in; g.CinPad = round_up(a.c_in, CSK_CPAD); g.Cout = a.c_out; g.Mpad = round_up(a.c_out, CSK_MT);
+        g.frames = n_skel; g.V = V; g.R = a.gcn_res_mode == CSK_RES_CONV ? 4 : 3; g.res_mode = a.gcn_res_mode;
+        g.vmagic = vmagic_of(V); g.mtiles = 1; g.qtiles = (unsigned)((Q + NP - 1) / NP); g.ksplit = 1; g.cper = g.CinPad; g.part = nullptr;
+        g.x_ring_slots = a.xin_slots; g.x_ring_slot0 = a.xin_slot0; g.y_ring_slots = a.y_slots; g.y_ring_slot0 = a.y_slot0;
+        g.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER);
+        StepParams &t = sp.b[i].t;
+        t = StepParams{};
+        t.ring = a.y_ring; t.w = a.tcn_w; t.xres = a.xin; t.wres = nullptr; t.bias = a.tcn_bias; t.out = a.out;
+        t.C = a.c_out; t.Cpad = round_up(a.c_out, CSK_CPAD); t.Cout = a.c_out; t.Mpad = round_up(a.c_out, CSK_MT);
+        t.K = 9; t.slots = a.y_slots; t.head = a.y_slot0; t.head_step = 1; t.res_mode = a.res_mode;
+        t.Cres = a.res_mode ? a.c_in : 1; t.CresPad = round_up(t.Cres, CSK_CPAD); t.relu = 1; t.P = P; t.fast_epi = 1;
+        t.xres_slots = a.xin_slots; t.xres_slot0 = a.x_res_slot0; t.xres_step = 1; t.out_slots = a.out_slots; t.out_slot0 = a.out_slot0;
+        t.ksplit = 1; t.cper = t.Cpad; t.part = nullptr; t.gx = (unsigned)((P + NP - 1) / NP); t.gy = 1; t.gz = 1;
+    }
+    void (*kern)(CoStackParams) = best_nb == 25 ? co_stack16_kernel<25> : co_stack16_kernel<18>;
+    const int NT = 16 * best_nb;
+    const size_t lds_g = (size_t)(8 * 4 * (80 + row16(NT)) + 8 * NT), lds_t = best_nb == 25 ? G16<25, 4, 1>::LDS_FLOATS : G16<18, 4, 1>::LDS_FLOATS;
+    const size_t lds = (lds_g > lds_t ? lds_g : lds_t) * sizeof(float);
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((P + NP - 1) / NP)), dim3(NTHREADS), lds, (hipStream_t)stream, sp);
+    return (int)hipGetLastError();
+}
+
+extern "C" int csk_co_stack_step_f32(int n_blocks, const csk_co_block_args *b, int n_skel, int V, int64_t P, void *stream) {
+    if (!b || n_blocks < 1 || n_blocks > CSK_CO_STACK_MAX) CSK_FAIL("co_stack_step: 1..%d blocks expected", CSK_CO_STACK_MAX);
+    for (int i = 0; i + 1 < n_blocks; ++i)
+        if (b[i + 1].xin != b[i].out || b[i + 1].xin_slots != b[i].out_slots || b[i + 1].xin_slot0 != b[i].out_slot0 ||
+            b[i + 1].c_in != b[i].c_out)
+            CSK_FAIL("co_stack_step: block %d does not read what block %d emits (ring, slot count, first slot, channels)", i + 1, i);
+    bool fusable = true;                                      // what csk_co_block_step_f32 would reject must not reach the kernel
+    for (int i = 0; i < n_blocks && fusable; ++i) {
+        const csk_co_block_args &a = b[i];
+        fusable = a.xin && a.gcn_w && a.gcn_bias && a.ell_src && a.ell_val && a.y_ring && a.tcn_w && a.tcn_bias && a.out && a.c_in > 0 &&
+                  a.c_out > 0 && n_skel > 0 && V >= 2 && V <= 64 && P >= (int64_t)n_skel * V && !(P & 3) && P < (1ll << 31) - 256 &&
+                  a.xin_slots >= 8 && a.y_slots >= 12 && a.out_slots >= 4 && a.xin_slot0 >= 0 && a.xin_slot0 < a.xin_slots &&
+                  a.y_slot0 >= 0 && a.y_slot0 < a.y_slots && a.out_slot0 >= 0 && a.out_slot0 < a.out_slots && a.x_res_slot0 >= 0 &&
+                  a.x_res_slot0 < a.xin_slots && (a.gcn_res_mode == CSK_RES_IDENTITY || a.gcn_res_mode == CSK_RES_CONV) &&
+                  (a.gcn_res_mode != CSK_RES_IDENTITY || a.c_in == a.c_out) && (a.res_mode == CSK_RES_NONE || a.res_mode == CSK_RES_IDENTITY) &&
+                  (a.res_mode != CSK_RES_IDENTITY || a.c_in == a.c_out) && a.ell_w >= 1 && a.ell_w <= V && a.ell_cnt[0] >= 0 &&
+                  a.ell_cnt[1] >= 0 && a.ell_cnt[2] >= 0 && a.ell_cnt[2] <= a.ell_w &&
+                  !(((uintptr_t)a.xin | (uintptr_t)a.y_ring | (uintptr_t)a.out) & 15);
+    }
+    if (fusable && n_blocks > 1) {
+        const int rc = csk_launch_co_stack16(n_blocks, b, n_skel, V, P, stream);
+        if (rc != -2) return rc;
+    }
+    for (int i = 0; i < n_blocks; ++i) {                      // per block (argument errors are reported from there)
+        const csk_co_block_args &a = b[i];
+        if (const int rc = csk_co_block_step_f32(a.xin, a.xin_slots, a.xin_slot0, a.c_in, a.gcn_w, a.gcn_bias, a.ell_src, a.ell_val, a.ell_cnt,
+                                                 a.ell_w, a.gcn_res_mode, a.y_ring, a.y_slots, a.y_slot0, a.tcn_w, a.tcn_bias, a.res_mode,
+                                                 a.x_res_slot0, a.out, a.out_slots, a.out_slot0, a.c_out, n_skel, V, P, stream))
+            return rc;
+    }
+    return 0;
 }

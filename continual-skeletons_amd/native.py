@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 # name -> argtypes; mirrors include/cskel.h line by line
@@ -31,6 +31,7 @@ SIGNATURES = {
     "csk_agcn_attention_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _l, _l, _i, _l, _p],
     "csk_agcn_embed_attention_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     "csk_tcn_step_f32": [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _p, _p],
+    "csk_co_stack_step_f32": [_i, _p, _i, _i, _l, _p],
     "csk_co_block_step_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _l, _p],
     "csk_co_spatial_pool_f32": [_p, _p, _i, _i, _i, _l, _p],
     "csk_co_window_mean_f32": [_p, _p, _l, _i, _i, _i, _p],

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 13
+#define CSK_ABI_VERSION 14
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -253,9 +253,9 @@ int csk_agcn_embed_attention_f32(const float *x, const float *w_pairs, const flo
  *  All ring bases 16-byte aligned, P % 4 == 0.
  *  ksplit > 1: the channel axis is cut into up to ksplit ranges computed by separate workgroups into `partial`
  *  ([n_emit * ksplit][c_out][P] floats, 16-byte aligned) and summed in a fixed order by a second kernel that also
- *  applies bias / identity residual / ReLU.  Used (a) by the 256-channel blocks always (ksplit = 3: three times as many
- *  tiles a third as long fill the GPU better than 800 tiles of 295 k MFMA cycles) and (b) in latency mode for few
- *  streams, where one workgroup per tile would walk the whole K loop alone.  Results differ from ksplit = 1 by fp32
+ *  applies bias / identity residual / ReLU.  Used in latency mode for few streams, where one workgroup per tile would walk
+ *  the whole K loop alone (rounds 2-5 also split the 256-channel blocks in 3 in the default mode; the slot-balanced tiles of
+ *  csrc/step16.hip made that unnecessary).  Results differ from ksplit = 1 by fp32
  *  summation order only; for a given ksplit they do not depend on n_emit or P.
  */
 int csk_tcn_step_f32(const float *ring, int slots, int head, int head_step, int n_emit, const float *w,
@@ -283,6 +283,31 @@ int csk_co_block_step_f32(const float *xin, int xin_slots, int xin_slot0, int c_
                           int ell_w, int gcn_res_mode, float *y_ring, int y_slots, int y_slot0, const float *tcn_w,
                           const float *tcn_bias, int res_mode, int x_res_slot0, float *out, int out_slots, int out_slot0,
                           int c_out, int n_skel, int V, int64_t P, void *stream);
+
+/*
+ * A STACK of consecutive blocks of that kind in one launch (round 6): csk_co_block_step_f32 for block 0, then for block 1 on
+ * block 0's output ring, ... -- n_blocks <= CSK_CO_STACK_MAX.  Block i + 1's `xin` must be block i's `out` (same slot counts),
+ * its new frames the slots block i emits into.  A workgroup owns the same positions (whole skeletons) of the four frames
+ * through every block: no workgroup depends on another (step mode has no temporal halo), stage outputs travel through the
+ * state rings and L2.  Bitwise the results of the per-block calls.  Needs the slot-balanced tile family (csrc/step16.hip:
+ * V = 25 or 18 joints, c_out a multiple of 4, rings below 4 GB); otherwise (or with one block) it IS the per-block calls.
+ */
+#define CSK_CO_STACK_MAX 4
+typedef struct csk_co_block_args {          /* the arguments of csk_co_block_step_f32 that differ per block */
+    const float *xin;
+    int32_t xin_slots, xin_slot0, c_in;
+    const float *gcn_w, *gcn_bias;
+    const int32_t *ell_src;
+    const float *ell_val;
+    int32_t ell_cnt[3], ell_w, gcn_res_mode;
+    float *y_ring;
+    int32_t y_slots, y_slot0;
+    const float *tcn_w, *tcn_bias;
+    int32_t res_mode, x_res_slot0;
+    float *out;
+    int32_t out_slots, out_slot0, c_out;
+} csk_co_block_args;
+int csk_co_stack_step_f32(int n_blocks, const csk_co_block_args *blocks, int n_skel, int V, int64_t P, void *stream);
 
 /* spatial_pool of CoModelBase (models/base.py:84) on a channel-major frame: feat[n, c] = mean of the MV = M*V
  * positions of stream n.  h (C, P); feat (N, C). */

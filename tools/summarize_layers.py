@@ -23,7 +23,7 @@ import workmodel as wm  # noqa: E402
 
 
 def short(name):
-    for k in ("tcn_step16_kernel", "gcn16_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
+    for k in ("co_stack16_kernel", "tcn_step16_kernel", "gcn16_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_sparse_kernel", "gcn_stage_kernel", "tcn_stage_kernel", "tcn_step_kernel", "pool_kernel", "co_block_kernel", "input_norm_kernel",
               "input_norm_frames_kernel", "co_head_kernel", "gcn_reduce_kernel", "co_spatial_pool_kernel", "co_window_mean_kernel", "fc_kernel", "step_reduce_kernel", "agcn_attention_step_kernel",
               "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel", "agcn_attention_kernel", "agcn_logits_partial_kernel", "agcn_softmax_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "gcn_stage_dense_kernel", "gcn_stage_dense2_kernel"):
         if k in name:
@@ -39,6 +39,8 @@ def klass(name):
         return "g"
     if "tcn_step" in name or "tcn_stage" in name or "tcn_split" in name:
         return "t"
+    if "co_stack" in name:
+        return "s"
     if "co_block" in name:
         return "f"
     if "input_norm" in name:
@@ -55,6 +57,7 @@ def main():
     ap.add_argument("--shards", type=int, default=1)
     ap.add_argument("--fpl", type=int, default=4)
     ap.add_argument("--note", default="")
+    ap.add_argument("--stack-blocks", type=int, default=3, help="blocks one co_stack16_kernel launch covers (CoST-GCN: layers 2-4)")
     ap.add_argument("--mode", default="online", choices=["online", "clip"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--model", default="stgcn", choices=["stgcn", "agcn"],
@@ -95,7 +98,7 @@ def main():
             prev_i = k == "i"
             if cur is not None:
                 cur.append(r)
-        good = [c for c in cycles if sum(klass(r["Kernel_Name"]) in "tf" for r in c) == tcn_per_cycle]
+        good = [c for c in cycles if sum((klass(r["Kernel_Name"]) in "tf") + a.stack_blocks * (klass(r["Kernel_Name"]) == "s") for r in c) == tcn_per_cycle]
         if len(good) < a.cycles:
             continue
         used_streams += 1
@@ -124,12 +127,14 @@ def main():
                     else:
                         per_layer[li]["e"].append(ms)
                     continue
-                if k in "tf":
+                if k in "tfs":
                     seen_a = False
-                if k in "gtf" and li < 10:
+                if k in "gtfs" and li < 10:
                     per_layer[li][k].append(ms)
                     if k in "tf":
                         li += 1
+                    elif k == "s":
+                        li += a.stack_blocks
                 else:
                     oth += ms
             cyc_kernel_ms.append(tot)
@@ -161,11 +166,16 @@ def main():
     csv_rows = []
     sums = dict(g=[0.0, 0.0], t=[0.0, 0.0])
     for i, (pl, lw) in enumerate(zip(per_layer, layers)):
-        for k in "eagtf":
+        for k in "eagtfs":
             if not pl[k]:
                 continue
             avg = sum(pl[k]) / len(pl[k])
-            if k == "e":
+            if k == "s":           # one launch for layers i .. i + stack_blocks - 1 (graph conv + temporal step of each)
+                grp = layers[i:i + a.stack_blocks]
+                alg = sum(l["gcn_macs"] + l["agg_dense"] + l["tcn_macs"] for l in grp)
+                ex = sum(l["gcn_macs"] + l["agg_sparse"] + l["tcn_macs"] for l in grp)
+                cnt = lw["emissions"]
+            elif k == "e":
                 alg = ex = lw["embed_macs"]
                 cnt = lw["frames_in"]
             elif k == "a":
@@ -183,7 +193,8 @@ def main():
                 cnt = lw["emissions"]
             alg, ex = 2e-9 * alg * n_skel, 2e-9 * ex * n_skel
             tf = alg / avg
-            name = {"e": "embed 1x1", "a": "attention" if pl["e"] else "embed + attention", "g": "gcn", "t": "tcn_stage" if clip else "tcn_step", "f": "fused"}[k]
+            name = {"e": "embed 1x1", "a": "attention" if pl["e"] else "embed + attention", "g": "gcn", "t": "tcn_stage" if clip else "tcn_step", "f": "fused",
+                    "s": f"fused stack L{i + 1}-L{i + a.stack_blocks}"}[k]
             L.append(f"| L{i + 1} {lw['ci']}->{lw['co']} s{lw['stride']} | {name} | {cnt} | {len(pl[k])} | {avg:.4f} | {alg:.2f} ({ex:.2f}) | {tf:.1f} | {tf / peak:.3f} | {ex / avg:.1f} | {ex / avg / peak:.3f} |")
             csv_rows.append(dict(layer=i + 1, c_in=lw["ci"], c_out=lw["co"], stride=lw["stride"], stage=name, launches=len(pl[k]),
                                  avg_ms=round(avg, 5), gflop_alg=round(alg, 3), gflop_exec=round(ex, 3), tflops_alg=round(tf, 2),
