@@ -614,6 +614,7 @@ extern "C" int csk_tcn_step_f32(const float *ring, int slots, int head, int head
     if (((uintptr_t)ring | (uintptr_t)(x_res ? x_res : ring)) & 15) CSK_FAIL("tcn_step: state pointers must be 16-byte aligned");
     StepParams p;
     p.stagger = 0;
+    p.stamps = nullptr;
     p.ring = ring; p.w = w; p.xres = x_res ? x_res : ring; p.wres = w_res; p.bias = bias; p.out = out;
     p.C = c; p.Cpad = round_up(c, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
     p.K = k; p.slots = slots; p.head = head; p.head_step = head_step; p.res_mode = res_mode;

@@ -34,7 +34,7 @@ namespace {
 constexpr int64_t CUS = 256;
 // start stagger of the odd-slot workgroup in units of 64 cycles (stagger_odd_slot); CSK_*_STAGGER under CSK_DIAG=1 overrides
 // (value + 1: 1 = off)
-constexpr int GCN16_STAGGER = 64, TCN16_STAGGER = 0;
+constexpr int GCN16_STAGGER = 0, TCN16_STAGGER = 0;       // swept in round 6: no effect (+- 0.1 %)
 inline int stagger_units(const char *env, int dflt) {
     const int v = csk_diag_int(env);
     return v > 0 ? v - 1 : dflt;
@@ -269,6 +269,10 @@ __device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, co
     f32x4 acc[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // diagnostic (p.stamps): per wave the cycles of the three parts of a chunk summed over the K loop, per workgroup start /
+    // loop start / loop end / end
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, ph0 = 0, ph1 = 0, ph2 = 0, tq = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
 
     // fragment bases: weights (B operand) lane (n = l15 -> output channel, k = kq), activations (A operand) lane (i = l15 ->
     // position inside the column block, k = kq)
@@ -284,11 +288,14 @@ __device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, co
         ws.issue(wbase);
         if (TAIL && KCH > p.C) rs.issue_tail(rbase, 0, p.C, P, tid);
         else rs.issue(rbase);
+        if (p.stamps) st1 = tq = __builtin_amdgcn_s_memtime();
         for (int c0 = 0; c0 < p.Cpad; c0 += KCH) {
             __syncthreads();
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
             ws.commit(Wl);
             rs.commit(Bl);
             __syncthreads();
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
             // next chunk's loads in three bursts between the three tap segments; past the end the last chunk is loaded again
             // into the (then dead) staging registers so that the K loop stays one basic block
             const int cn = min(c0 + KCH, p.Cpad - KCH);
@@ -313,7 +320,9 @@ __device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, co
 #pragma unroll
             for (int r = 6; r < 9; ++r) mfma16_tap<NB>(wl_lane + r * KCH * LDW, bl_lane + G::slot_lds(r), acc);
             __builtin_amdgcn_s_setprio(0);
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
         }
+        if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
     }
     // ---- phase 2: 1x1 residual conv on the delayed block input (one "tap" per emission: the E residual frames back to back)
     if (p.res_mode == CSK_RES_CONV) {
@@ -353,6 +362,12 @@ __device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, co
     const int nval = (int)min((int64_t)NP, P - p0);                             // positions of the tile inside the row (multiple of 4)
     epilogue16<NB, E, NP>(acc, p.bias, p.Cout, m0 + wave * 16 + l15, kq, p.res_mode == CSK_RES_IDENTITY, p.relu != 0, p.xres, p.out,
                           xslot, oslot, P, P, p0, nval, nval);
+    if (p.stamps && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the epilogue's stores have left
+        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = ph0; o[5] = ph1; o[6] = ph2;
+        o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+    }
 }
 
 template <int NB, int E, int HS, bool TAIL>
@@ -441,6 +456,7 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
         // ---- P1: aggregate chunk c, commit its weights, load the next chunk's.  Per column the 8 x 6 (+ 8) source values are
         // read first, all in flight together (the aggregated rows and the x rows share LDS: interleaved with the writes the
         // reads would be issued six at a time, each batch behind the previous one's latency)
+        if (!(p.stagger & 0x10000)) {                          // (diagnostic: CSK_GCN16_SKIP=1 times the kernel without its aggregation phase)
         constexpr int KB = (CONVRES && NB > 20) ? 2 : 8;      // channels whose source values are in flight together (register budget)
 #pragma unroll
         for (int n = 0; n < NCOL; ++n) {
@@ -477,6 +493,7 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }
         ws.commit(Wl);
         ws.issue(wbase + (size_t)min(c + 1, nchunks - 1) * KCG * p.Mpad);
         __syncthreads();
@@ -484,8 +501,10 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
         xs.commit(Xs);
         issue_x(c + 2);
         __builtin_amdgcn_s_setprio(1);
+        if (!(p.stagger & 0x20000)) {                          // (diagnostic: CSK_GCN16_SKIP=2: without its MFMA phase)
 #pragma unroll
         for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
+        }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
@@ -507,7 +526,7 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
 template <int NB, int F, bool CONVRES>
 __global__ __launch_bounds__(NTHREADS, 2) void gcn16_kernel(const GcnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    stagger_odd_slot(p.stagger);
+    stagger_odd_slot(p.stagger & 0xffff);
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
     gcn16_tile<NB, F, CONVRES>(p, (int)(wid % p.mtiles), (int)((wid / p.mtiles) % p.qtiles), (int)(wid / (p.mtiles * p.qtiles)), smem);
 }
@@ -559,7 +578,7 @@ int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
     const int64_t grid = (int64_t)p.qtiles * p.mtiles * (n_seg / F);
     if (grid >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
     void (*kern)(GcnParams) = p.R == 4 ? gcn16_kernel<NB, F, true> : gcn16_kernel<NB, F, false>;
-    p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER);
+    p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER) | (csk_diag_int("CSK_GCN16_SKIP") << 16);
     const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 8 * NT) * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, p);
@@ -573,6 +592,7 @@ int launch16(StepParams p, int n_emit, hipStream_t s) {
     if ((int64_t)p.gx * p.gy * p.gz >= (1ll << 31)) CSK_FAIL("tcn_step: grid too large");
     const bool tail = (p.C % G::KCH) != 0 || (p.res_mode == CSK_RES_CONV && (p.Cres % G::KR) != 0);
     p.stagger = stagger_units("CSK_TCN16_STAGGER", TCN16_STAGGER);
+    p.stamps = csk_diag_stamps();
     void (*kern)(StepParams) = tail ? tcn_step16_kernel<NB, E, HS, true> : tcn_step16_kernel<NB, E, HS, false>;
     const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
@@ -691,6 +711,7 @@ int csk_launch_co_stack16(int n_blocks, const csk_co_block_args *b, int n_skel, 
         t.K = 9; t.slots = a.y_slots; t.head = a.y_slot0; t.head_step = 1; t.res_mode = a.res_mode;
         t.Cres = a.res_mode ? a.c_in : 1; t.CresPad = round_up(t.Cres, CSK_CPAD); t.relu = 1; t.P = P; t.fast_epi = 1;
         t.xres_slots = a.xin_slots; t.xres_slot0 = a.x_res_slot0; t.xres_step = 1; t.out_slots = a.out_slots; t.out_slot0 = a.out_slot0;
+        t.stamps = nullptr;
         t.ksplit = 1; t.cper = t.Cpad; t.part = nullptr; t.gx = (unsigned)((P + NP - 1) / NP); t.gy = 1; t.gz = 1;
     }
     void (*kern)(CoStackParams) = best_nb == 25 ? co_stack16_kernel<25> : co_stack16_kernel<18>;

@@ -17,6 +17,7 @@ struct StepParams {
     float *part;       // and writes raw partial sums to part[(emission*ksplit + ks)][Cout][P]; 1 = off
     int64_t P;
     int stagger;       // step16.hip: start delay of the odd-slot workgroup of a CU, x 64 cycles
+    unsigned long long *stamps;   // step16.hip diagnostic (env CSK_STAMPS=<device ptr> under CSK_DIAG=1): s_memtime stamps, tools/stamp16_probe.py
 };
 
 // step16.hip: the slot-balanced tile family (64 channels x 16*NB columns, v_mfma_f32_16x16x4_f32).  Both return -2 when the

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave s_memtime stamps of tcn_step16_kernel at the online shapes (1024 NTU streams): where a chunk's cycles go
+(wait at the first barrier / commit + second barrier / MFMA segments with the next chunk's loads) and prologue / epilogue."""
+import os, sys
+os.environ["CSK_DIAG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+import _bootstrap
+pkg = _bootstrap.load()
+from continual_skeletons_amd import native
+dev = torch.device("cuda:0")
+P = 1024 * 2 * 25
+lib = native.lib()
+for (c, n_emit, hs, res) in [(64, 4, 1, 1), (64, 4, 1, 0), (128, 2, 1, 1), (256, 1, 1, 1)]:
+    tc = pkg.TemporalConvolution(c, c, kernel_size=9, stride=1, padding=4).eval().to(dev)
+    ops = tc._packed_ops(dev)
+    slots = 16
+    ring = torch.rand((slots, c, P), device=dev)
+    xres = torch.rand((8, c, P), device=dev)
+    out = torch.empty((4, c, P), device=dev)
+    nwg = 512
+    stamps = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
+    for it in range(3):
+        if it == 2:
+            os.environ["CSK_STAMPS"] = str(stamps.data_ptr())
+        rc = lib.csk_tcn_step_f32(native.ptr(ring), slots, 11, hs, n_emit, native.ptr(ops["w"]), native.ptr(xres) if res else None, 8, 0, 1,
+                                  None, native.ptr(ops["bias"]), native.ptr(out), 4, 0, c, c, P, 9, res, c if res else 0, 1, 1, None,
+                                  native.stream_of(ring))
+        native.check(rc, "csk_tcn_step_f32")
+        torch.cuda.synchronize()
+    os.environ.pop("CSK_STAMPS", None)
+    st = stamps.cpu().numpy().reshape(nwg, 4, 8)
+    chunks = c // 4
+    pro, loop, epi = st[:, :, 1] - st[:, :, 0], st[:, :, 2] - st[:, :, 1], st[:, :, 3] - st[:, :, 2]
+    span = st[:, :, 3].max() - st[:, :, 0].min()
+    print(f"STAMP16 C={c} n_emit={n_emit} res={res}: span {span} ticks | per wave: prologue {np.median(pro):.0f} loop {np.median(loop):.0f} epilogue {np.median(epi):.0f} "
+          f"| per chunk: barrier1 wait {np.median(st[:, :, 4]) / chunks:.0f}  commit+barrier2 {np.median(st[:, :, 5]) / chunks:.0f}  mfma+issue {np.median(st[:, :, 6]) / chunks:.0f} "
+          f"(225 MFMAs = 7200 cycles alone, 14400 shared) | start spread {np.percentile(st[:, :, 0], 99) - st[:, :, 0].min():.0f} | end spread {st[:, :, 3].max() - np.percentile(st[:, :, 3], 1):.0f}")
