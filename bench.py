@@ -553,15 +553,18 @@ def main():
                     help="timed launch cycles of the online workload (default 100 cycles of 4 frames = 400 timed frames per stream, SURVEY 8d)")
     ap.add_argument("--kernel-cycles", type=int, default=17,
                     help="cycles of the single-shard pass that times every tcn_step_kernel launch with HIP events (6 launches per cycle: 17 -> 102)")
-    ap.add_argument("--stream-shards", type=int, default=2, help="independent stream shards on separate HIP streams")
+    ap.add_argument("--stream-shards", type=int, default=1,
+                    help="independent stream shards on separate HIP streams (rounds 2-5 ran 2: their tiles cut a launch into 800 k pieces "
+                         "for 512 slots and a second shard filled the tail rounds; the slot-balanced tiles of csrc/step16.hip make every "
+                         "launch of the 1024-stream cycle one full round, and one shard measures faster)")
     ap.add_argument("--frames-per-launch", type=int, default=4, help="frames advanced per launch cycle of the online workload")
     ap.add_argument("--config5-batch", type=int, default=1024,
                     help="clips per GPU of the configs[4] leg (8192 / 8 GPUs), run when more than one rank is launched")
     ap.add_argument("--config4-batch", type=int, default=64, help="A-GCN clips of the configs[3] clip leg")
     ap.add_argument("--config4-streams", type=int, default=1024, help="CoAGCN streams of the configs[3] online leg")
-    ap.add_argument("--config4-shards", type=int, default=3,
-                    help="stream shards of the CoAGCN leg (its launches are smaller than CoST-GCN's: three interleave better than two, "
-                         "measured 982 k -> 1015 k frames/s; four exceed the hardware queues)")
+    ap.add_argument("--config4-shards", type=int, default=1,
+                    help="stream shards of the CoAGCN leg (rounds 3-5 ran three; with the slot-balanced temporal-step tiles one shard "
+                         "measures fastest: 1039 k frames/s against 1034 k / 967 k with two / three)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the opt-in bf16x3 precision-mode leg")
     ap.add_argument("--no-config5-leg", action="store_true", help="N = 1 only: skip the configs[4] per-GPU shard leg (1024 clips in one forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -818,14 +821,15 @@ def main():
                      "unit": "frames/s", "streams_per_gpu": args.streams, "stream_shards": args.stream_shards, "frames_per_launch": args.frames_per_launch, "ms_per_frame_step": round(sdt / args.step_cycles / args.frames_per_launch * 1e3, 4),
                      "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes[0] / 1e9, 3),
                      "split_k_scratch_GB_per_gpu": round(sbytes[1] / 1e9, 3),
-                     "roofline": {"bound": "mfma", "kernel": "tcn_step_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "roofline": {"bound": "mfma", "kernel": "tcn_step16_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,
                                   "avg_launch_ms": round(stcn_ms / max(1, sn), 4),
                                   "flops_per_launch": tfl / len(step_layers),
                                   "timing": "single stream shard, launches driven from Python with HIP events around every "
-                                            f"tcn_step_kernel launch (blocks 5-10; blocks 1-4 use the fused block kernel) of {kcycles} cycles of "
+                                            f"csk_tcn_step_f32 launch (tcn_step16_kernel; blocks 5-10 -- blocks 1-4 advance through the fused block / "
+                                            f"stack entry points) of {kcycles} cycles of "
                                             "4 frames: the launch shape of tools/online_pass.py --shards 1, whose rocprofv3 per-layer "
-                                            "table is profiles/r05_online_1shard.md (rows L5-L10 tcn_step)",
+                                            "table is profiles/r06_online_1shard.md (rows L5-L10 tcn_step)",
                                   "traffic": straffic["hbm_bytes_per_launch"] if straffic else None,
                                   "traffic_source": (f"{straffic.get('source')} (committed PMC passes, not collected by this run)")
                                   if straffic else "no committed PMC pass at this stream count"},

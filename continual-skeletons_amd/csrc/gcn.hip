@@ -793,7 +793,7 @@ static int gcn_stage_impl(const float *x, float *y, const float *w, const float 
         p.ell_cnt[i] = ell_cnt[i];
     }
     p.ell_w = ell_w; p.adj_seg_stride = adj_seg_stride;
-    p.x_ring_slots = p.y_ring_slots = 1 << 30; p.x_ring_slot0 = p.y_ring_slot0 = 0; p.stagger = 0;
+    p.x_ring_slots = p.y_ring_slots = 1 << 30; p.x_ring_slot0 = p.y_ring_slot0 = 0; p.stagger = 0; p.stamps = nullptr;
     p.x_seg_stride = x_seg_stride; p.x_chan_stride = x_chan_stride;
     p.y_seg_stride = y_seg_stride; p.y_chan_stride = y_chan_stride;
     p.Cin = c_in; p.CinPad = round_up(c_in, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);

@@ -25,6 +25,7 @@ struct GcnParams {
     // step16.hip: segment s of the launch is slot (ring_slot0 + s) % ring_slots of x / y (plain calls: no wrap, 1 << 30 slots)
     int x_ring_slots, x_ring_slot0, y_ring_slots, y_ring_slot0;
     int stagger;         // step16.hip: start delay of the odd-slot workgroup of a CU, x 64 cycles
+    unsigned long long *stamps;   // step16.hip diagnostic (CSK_STAMPS under CSK_DIAG=1): s_memtime phase sums per wave, tools/stamp16_probe.py
 };
 
 // gcn_dense.hip: dense (per-segment or per-frame) adjacency with an even joint count V <= 18; returns -2 when the shape is

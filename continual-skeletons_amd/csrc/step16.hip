@@ -452,6 +452,8 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     xs.commit(Xs);
     issue_x(1);
     __syncthreads();
+    unsigned long long gp0 = 0, gp1 = 0, gp2 = 0, gp3 = 0, gp4 = 0, gq = 0, gst0 = 0;   // diagnostic phase sums (p.stamps only)
+    if (p.stamps) gst0 = gq = __builtin_amdgcn_s_memtime();
     for (int c = 0; c < nchunks; ++c) {
         // ---- P1: aggregate chunk c, commit its weights, load the next chunk's.  Per column the 8 x 6 (+ 8) source values are
         // read first, all in flight together (the aggregated rows and the x rows share LDS: interleaved with the writes the
@@ -496,17 +498,27 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
         }
         ws.commit(Wl);
         ws.issue(wbase + (size_t)min(c + 1, nchunks - 1) * KCG * p.Mpad);
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp0 += t - gq; gq = t; }
         __syncthreads();
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp1 += t - gq; gq = t; }
         // ---- P2: x rows of chunk c + 1 -> LDS, chunk c + 2 -> registers, MFMAs of chunk c
         xs.commit(Xs);
         issue_x(c + 2);
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp2 += t - gq; gq = t; }
         __builtin_amdgcn_s_setprio(1);
         if (!(p.stagger & 0x20000)) {                          // (diagnostic: CSK_GCN16_SKIP=2: without its MFMA phase)
 #pragma unroll
         for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
         }
         __builtin_amdgcn_s_setprio(0);
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp3 += t - gq; gq = t; }
         __syncthreads();
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp4 += t - gq; gq = t; }
+    }
+    if (p.stamps && lane == 0) {
+        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = gst0; o[1] = gq; o[2] = gp0; o[3] = gp1; o[4] = gp2; o[5] = gp3; o[6] = gp4;
+        o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
     }
     unsigned oslot[F], xslot[F];
 #pragma unroll
@@ -579,6 +591,7 @@ int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
     if (grid >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
     void (*kern)(GcnParams) = p.R == 4 ? gcn16_kernel<NB, F, true> : gcn16_kernel<NB, F, false>;
     p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER) | (csk_diag_int("CSK_GCN16_SKIP") << 16);
+    p.stamps = csk_diag_stamps();
     const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 8 * NT) * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, p);
@@ -704,6 +717,7 @@ int csk_launch_co_stack16(int n_blocks, const csk_co_block_args *b, int n_skel, 
         g.vmagic = vmagic_of(V); g.mtiles = 1; g.qtiles = (unsigned)((Q + NP - 1) / NP); g.ksplit = 1; g.cper = g.CinPad; g.part = nullptr;
         g.x_ring_slots = a.xin_slots; g.x_ring_slot0 = a.xin_slot0; g.y_ring_slots = a.y_slots; g.y_ring_slot0 = a.y_slot0;
         g.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER);
+        g.stamps = nullptr;
         StepParams &t = sp.b[i].t;
         t = StepParams{};
         t.ring = a.y_ring; t.w = a.tcn_w; t.xres = a.xin; t.wres = nullptr; t.bias = a.tcn_bias; t.out = a.out;

@@ -36,3 +36,25 @@ for (c, n_emit, hs, res) in [(64, 4, 1, 1), (64, 4, 1, 0), (128, 2, 1, 1), (256,
     print(f"STAMP16 C={c} n_emit={n_emit} res={res}: span {span} ticks | per wave: prologue {np.median(pro):.0f} loop {np.median(loop):.0f} epilogue {np.median(epi):.0f} "
           f"| per chunk: barrier1 wait {np.median(st[:, :, 4]) / chunks:.0f}  commit+barrier2 {np.median(st[:, :, 5]) / chunks:.0f}  mfma+issue {np.median(st[:, :, 6]) / chunks:.0f} "
           f"(225 MFMAs = 7200 cycles alone, 14400 shared) | start spread {np.percentile(st[:, :, 0], 99) - st[:, :, 0].min():.0f} | end spread {st[:, :, 3].max() - np.percentile(st[:, :, 3], 1):.0f}")
+
+# graph conv (gcn16_kernel): phase sums per wave and chunk of 8 channels
+A = pkg.ntu_graph().A
+for (ci, co, frames) in [(64, 64, 4), (128, 128, 2), (256, 256, 1)]:
+    g = pkg.GraphConvolution(ci, co, A).eval().to(dev)
+    x = torch.rand((frames, ci, P), device=dev)
+    y = torch.empty((frames, co, P), device=dev)
+    nwg = 512
+    stamps = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
+    for it in range(3):
+        if it == 2:
+            os.environ["CSK_STAMPS"] = str(stamps.data_ptr())
+        g.stage(x, y, n_seg=frames, frames=2048, x_strides=(ci * P, P), y_strides=(co * P, P))
+        torch.cuda.synchronize()
+    os.environ.pop("CSK_STAMPS", None)
+    st = stamps.cpu().numpy().reshape(nwg, 4, 8)
+    chunks = max(ci, 16) // 8
+    hw = st[:, 0, 7]
+    print(f"STAMP16 gcn {ci}->{co} x{frames}: loop {np.median(st[:, :, 1] - st[:, :, 0]):.0f} cycles = {chunks} chunks | per chunk and wave: aggregation+W commit {np.median(st[:, :, 2]) / chunks:.0f}  "
+          f"barrier1 wait {np.median(st[:, :, 3]) / chunks:.0f}  x commit+issue {np.median(st[:, :, 4]) / chunks:.0f}  mfma {np.median(st[:, :, 5]) / chunks:.0f} (150 MFMAs = 4800 alone, 9600 shared)  "
+          f"barrier2 wait {np.median(st[:, :, 6]) / chunks:.0f} | wave-slot parity of wave 0: {np.bincount((hw & 1).astype(int), minlength=2)} | start offset between odd and even slots "
+          f"{np.median(st[(hw & 1) == 1, 0, 0]) - np.median(st[(hw & 1) == 0, 0, 0]) if ((hw & 1) == 1).any() and ((hw & 1) == 0).any() else float('nan'):.0f}")
