@@ -178,6 +178,7 @@ def run_step_workload(pkg, dev, streams, cycles, warm_cycles, rank, world, paral
     def make():
         net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
         net.use_native_plan = native_plan     # False: launches are driven from Python so that they can be timed one by one
+        net.set_max_cycle(min(8, max(4, fpl)))   # rings sized for the cycles this leg issues (warm-up runs single frames)
         randomise_(net, seed=0)
         return net.to(dev)
     eng = parallel.StreamShards(make, streams, shards, dev)
@@ -310,6 +311,7 @@ def run_config4(pkg, dev, parallel, batch=64, streams=1024, shards=2, cpu_thread
 
     def make():
         co = pkg.CoAGcn(A, shape, 400).eval()
+        co.set_max_cycle(4)                      # this leg issues 4-frame cycles
         randomise_(co, 0, attn_scale=1 / 18)
         return co.to(dev)
     eng = parallel.StreamShards(make, streams, shards, dev)

@@ -510,16 +510,17 @@ class CoStGcn(_Folded):
     def _bind(self, n, device):
         c_in, _, v, m = self.input_shape
         p = _round4(n * m * v)
-        xin = torch.zeros((in_slots(MAX_CYCLE), c_in, p), device=device, dtype=torch.float32)
+        mc = self.max_cycle
+        xin = torch.zeros((in_slots(mc), c_in, p), device=device, dtype=torch.float32)
         self._xin0, self._p, self._n = xin, p, n
-        # frames one launch of block i can receive / emit: MAX_CYCLE input frames / cumulative temporal stride.  They size
+        # frames one launch of block i can receive / emit: max_cycle input frames / cumulative temporal stride.  They size
         # the rings (y: 8 + max_in, output = next block's input history: 4 + its max_in) and the split-K scratch, which is
         # ONE buffer sized by its largest user (launches of a model are stream-ordered)
         recv, emits, cum = [], [], 1
         for i in range(10):
-            recv.append(max(1, MAX_CYCLE // cum))
+            recv.append(max(1, mc // cum))
             cum *= self.layers[f"layer{i + 1}"].stride
-            emits.append(max(1, MAX_CYCLE // cum))
+            emits.append(max(1, mc // cum))
         need = max(self.layers[f"layer{i + 1}"].scratch_floats(p, emits[i], recv[i]) for i in range(10))
         if need * 4 > self.LATENCY_SCRATCH_CAP_BYTES:
             raise RuntimeError(
@@ -538,6 +539,19 @@ class CoStGcn(_Folded):
         self._frames = self._feats = 0
         self._flushed = False
         self._build_plan(device)
+
+    max_cycle = MAX_CYCLE   # frames ONE forward_cycle may carry: sizes the state rings (set_max_cycle)
+
+    def set_max_cycle(self, frames: int = MAX_CYCLE):
+        """Largest launch cycle (1..8 frames) the state slab is sized for.  A block's rings hold the 8-frame window of its
+        temporal conv / the 4-frame residual lag PLUS the frames one launch brings (``max_cycle`` / cumulative stride), so the
+        default of 8 pays for cycles the 4-frames-per-launch mode never issues: 5.75 GB at 1024 NTU streams against 4.65 GB with
+        ``set_max_cycle(4)`` (SURVEY 8a's per-frame minimum: 3.25 GB).  Results do not depend on it (a frame lives in slot
+        s % depth, the kernels take the depths as arguments).  Takes effect from a clean state (the slab is re-bound)."""
+        if not isinstance(frames, int) or not 1 <= frames <= MAX_CYCLE:
+            raise ValueError(f"max_cycle must be an integer in [1, {MAX_CYCLE}]")
+        self.max_cycle = frames
+        self._n = None
 
     LATENCY_SCRATCH_CAP_BYTES = 1 << 30   # split-K scratch above which binding a slab in latency mode is refused
 
@@ -636,10 +650,10 @@ class CoStGcn(_Folded):
             if type(blk.gcn) is not GraphConvolution:      # adaptive graph conv: adjacency per skeleton frame (agcn.py)
                 a = blk.gcn.plan_operands(device)
                 adj = self.__dict__.get("_agcn_adj")
-                need = MAX_CYCLE * self._n * self.input_shape[3] * 3 * self.input_shape[2] ** 2      # [cycle frames][skeletons][3][V][V]
+                need = self.max_cycle * self._n * self.input_shape[3] * 3 * self.input_shape[2] ** 2      # [cycle frames][skeletons][3][V][V]
                 if adj is None or adj.numel() < need or adj.device != st.y.device:
                     adj = self.__dict__["_agcn_adj"] = torch.empty((need,), device=st.y.device, dtype=torch.float32)
-                L.agcn_inter, L.agcn_adj_frames = a["inter"], MAX_CYCLE
+                L.agcn_inter, L.agcn_adj_frames = a["inter"], self.max_cycle
                 L.agcn_w_pairs, L.agcn_b_pairs, L.agcn_a_sum = a["w_pairs"].data_ptr(), a["b_pairs"].data_ptr(), a["a_sum"].data_ptr()
                 L.agcn_adj = adj.data_ptr()
                 L.ell_val = None
@@ -727,8 +741,8 @@ class CoStGcn(_Folded):
         (None, 0) if none) and the list of predictions."""
         self._require_eval()
         frames = list(frames)
-        if not 1 <= len(frames) <= MAX_CYCLE:
-            raise ValueError(f"a cycle holds 1..{MAX_CYCLE} frames, got {len(frames)}")
+        if not 1 <= len(frames) <= self.max_cycle:
+            raise ValueError(f"a cycle holds 1..{self.max_cycle} frames (set_max_cycle), got {len(frames)}")
         x0 = frames[0]
         for x_t in frames:
             native.require_device_f32(x_t, "CoStGcn frame")

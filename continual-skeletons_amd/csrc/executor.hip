@@ -21,6 +21,7 @@ struct csk_co_plan {
     float *pool_ring, *pooled;
     long frames = 0, feats = 0;
     bool fuse = true;          // csk_co_block_step_f32 for the blocks that qualify
+    int max_cycle = CSK_CO_MAX_CYCLE;   // frames one cycle may carry = what the rings were sized for (xin0_slots - 4, at most 8)
 };
 
 extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int xin0_slots, int N, int C,
@@ -33,12 +34,14 @@ extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *lay
         snprintf(csk_err_buf(), 256, "co_plan_create: bad argument");
         return nullptr;
     }
-    if (xin0_slots < CSK_CO_IN_SLOTS(CSK_CO_MAX_CYCLE)) {
-        snprintf(csk_err_buf(), 256, "co_plan_create: the input ring needs >= %d slots, got %d", CSK_CO_IN_SLOTS(CSK_CO_MAX_CYCLE), xin0_slots);
+    if (xin0_slots < CSK_CO_IN_SLOTS(1)) {
+        snprintf(csk_err_buf(), 256, "co_plan_create: the input ring needs >= %d slots, got %d", CSK_CO_IN_SLOTS(1), xin0_slots);
         return nullptr;
     }
+    // the largest cycle the plan accepts is what the input ring was sized for: xin0_slots = CSK_CO_IN_SLOTS(max_cycle)
+    const int max_cycle = xin0_slots - CSK_CO_IN_SLOTS(0) < CSK_CO_MAX_CYCLE ? xin0_slots - CSK_CO_IN_SLOTS(0) : CSK_CO_MAX_CYCLE;
     // ring depths against the frames one launch of each layer can receive / emit (include/cskel.h: CSK_CO_Y_SLOTS, CSK_CO_IN_SLOTS)
-    for (int i = 0, max_in = CSK_CO_MAX_CYCLE; i < n_layers; ++i) {
+    for (int i = 0, max_in = max_cycle; i < n_layers; ++i) {
         const csk_co_layer &l = layers[i];
         if (l.stride < 1 || l.stride > 2) break;                              // reported by the per-layer checks below
         const int max_emit = max_in / l.stride > 0 ? max_in / l.stride : 1;
@@ -78,6 +81,7 @@ extern "C" csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *lay
         }
     }
     csk_co_plan *p = new csk_co_plan();
+    p->max_cycle = max_cycle;
     p->layers.assign(layers, layers + n_layers);
     p->cnt.resize(n_layers);
     p->xin0 = xin0; p->xin0_slots = xin0_slots; p->N = N; p->C = C; p->V = V; p->M = M; p->P = P;
@@ -266,7 +270,7 @@ static int run_blocks(csk_co_plan *p, int r, int *slot0, int *n_last, void *stre
 extern "C" int csk_co_plan_cycle(csk_co_plan *p, const float *const *frames, int r, float *logits, int *last_slot,
                                  int *n_feat, int *n_logits, void *stream) {
     if (!p || !frames || !logits || !last_slot || !n_feat || !n_logits) CSK_FAIL("co_plan_cycle: null pointer");
-    if (r < 1 || r > CSK_CO_MAX_CYCLE) CSK_FAIL("co_plan_cycle: r must be in [1, %d]", CSK_CO_MAX_CYCLE);
+    if (r < 1 || r > p->max_cycle) CSK_FAIL("co_plan_cycle: r must be in [1, %d] (the rings of this plan were sized for cycles of %d frames)", p->max_cycle, p->max_cycle);
     *n_feat = *n_logits = 0;
     *last_slot = 0;
     // A launch can fail half way through a cycle (bad pointer, launch error): the counters are then put

@@ -391,7 +391,9 @@ typedef struct csk_co_layer {
 
 typedef struct csk_co_plan csk_co_plan;
 
-/* xin0: [xin0_slots][C][P] input ring of layer 0 (xin0_slots >= CSK_CO_IN_SLOTS(CSK_CO_MAX_CYCLE)).
+/* xin0: [xin0_slots][C][P] input ring of layer 0.  xin0_slots = CSK_CO_IN_SLOTS(max_cycle) fixes the largest cycle the plan
+ * accepts (max_cycle = xin0_slots - 4, at most CSK_CO_MAX_CYCLE); every layer's rings are checked against it (max_in above
+ * with max_cycle in the place of CSK_CO_MAX_CYCLE): a slab for 4-frame cycles is 19 % smaller than one for 8-frame cycles.
  * pool_ring: [pool_size][N][feat_c]; pooled: [N][feat_c]. */
 csk_co_plan *csk_co_plan_create(int n_layers, const csk_co_layer *layers, float *xin0, int xin0_slots, int N, int C, int V, int M,
                                 int64_t P, const float *bn_scale, const float *bn_shift, int classes,

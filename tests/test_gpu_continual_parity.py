@@ -548,3 +548,28 @@ def test_fused_head_equals_the_three_launches_bitwise(n, c, mv, classes, window)
         native.check(lib.csk_co_head_step_f32(native.ptr(h), native.ptr(ring_b), native.ptr(pooled_b), native.ptr(w), native.ptr(b),
                                               native.ptr(logits_b), n, c, mv, P, window, head, count, 1, classes, stream), "head")
         assert torch.equal(ring_a, ring_b) and torch.equal(pooled_a, pooled_b) and torch.equal(logits_a, logits_b), step
+
+
+def test_max_cycle_4_slab_is_smaller_and_bitwise_the_same():
+    """CoStGcn.set_max_cycle(4): rings sized for 4-frame cycles (what bench.py's online leg issues) instead of 8 -- the same
+    predictions bit for bit, a smaller slab, cycles of 5 frames refused (Python and plan)."""
+    a, sd, x = g6_state_dict("ntu")
+    x = x[:2, :, :160].to(DEV)
+    big = pkg.CoStGcn(A, pool_size=4, pool_padding=1).eval()
+    small = pkg.CoStGcn(A, pool_size=4, pool_padding=1).eval()
+    for m in (big, small):
+        m.load_state_dict(sd, strict=True)
+    small.set_max_cycle(4)
+    big, small = big.to(DEV), small.to(DEV)
+    got, want = [], []
+    for t in range(0, 160, 4):
+        fr = [x[:, :, t + f].contiguous() for f in range(4)]
+        want += big.forward_cycle(fr)
+        got += small.forward_cycle(fr)
+    assert len(got) == len(want) >= 18 and all(torch.equal(g, w) for g, w in zip(got, want))
+    assert small.state_bytes() < 0.85 * big.state_bytes()           # 19 % smaller
+    assert small.layers["layer1"]._state.y.shape[0] == 12 and big.layers["layer1"]._state.y.shape[0] == 16
+    with pytest.raises(ValueError, match="1..4 frames"):
+        small.forward_cycle([x[:, :, f].contiguous() for f in range(5)])
+    with pytest.raises(ValueError):
+        small.set_max_cycle(9)

@@ -400,7 +400,15 @@ def test_fused_attention_entry_and_plan_validate_their_arguments_without_a_gpu()
     assert not create() and b"adaptive graph conv" in lib.csk_last_error()
     l.ell_w = 18
     # ring depths (include/cskel.h: CSK_CO_Y_SLOTS / CSK_CO_IN_SLOTS) and scratch capacities are part of the contract
-    assert not create(xin0_slots=11) and b"input ring needs >= 12" in lib.csk_last_error()
+    assert not create(xin0_slots=4) and b"input ring needs >= 5" in lib.csk_last_error()
+    # the input ring's depth fixes the largest cycle: 4 + 4 slots = cycles of <= 4 frames, for which a 12-slot y ring and a
+    # 4-slot output ring (last layer: its own emissions, >= 4) suffice; the same rings are too shallow for 8-frame cycles
+    l.y_slots, l.out_slots, l.agcn_adj_frames = 12, 4, 4
+    small = create(xin0_slots=8)
+    assert small
+    lib.csk_co_plan_destroy(C.c_void_p(small))
+    assert not create(xin0_slots=12) and b"rings too shallow" in lib.csk_last_error()
+    l.y_slots, l.out_slots, l.agcn_adj_frames = 16, 8, 8
     l.y_slots = 15
     assert not create() and b"rings too shallow" in lib.csk_last_error()
     l.y_slots, l.out_slots = 16, 7

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the PMC passes of tools/profile_r05.sh (gpurun_out/prof_<tag>/{sq,fetch,write}_<mode>) into
+"""Condense the PMC passes of tools/profile_r06.sh (gpurun_out/prof_<tag>/{sq,fetch,write}_<mode>) into
 profiles/<out>_pmc_summary.md: per kernel instantiation and precision mode -- launches, clock, MFMA-pipe busy fraction,
 waves per SIMD, wait fractions, HBM read / write MB per launch (FETCH_SIZE calibrated on input_norm_kernel, whose bytes
 are known: MI355X_MICROARCH.md HBM section) -- and refresh profiles/traffic_tcn_stage.json and traffic_tcn_step.json (what
@@ -21,7 +21,7 @@ def rows_of(pattern):
 
 
 def short(name):
-    for k in ("tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
+    for k in ("co_stack16_kernel", "tcn_step16_kernel", "gcn16_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
               "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel", "tcn_step_kernel", "co_block_kernel", "step_reduce_kernel", "co_head_kernel",
               "agcn_logits_partial_kernel", "agcn_softmax_kernel", "input_norm_kernel", "pool_kernel", "fc_kernel"):
         if k in name:
@@ -48,7 +48,7 @@ def pmc(d, sub):
 
 def main(tag, out_tag):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    L = [f"# PMC passes ({out_tag}): tools/profile_r05.sh -- `rocprofv3 --kernel-trace --pmc ...` of tools/clip_pass.py (batch 256, both precision "
+    L = [f"# PMC passes ({out_tag}): tools/profile_r06.sh -- `rocprofv3 --kernel-trace --pmc ...` of tools/clip_pass.py (batch 256, both precision "
          "modes), tools/agcn_prof.py (A-GCN, Kinetics shape, batch 64) and tools/online_pass.py --shards 1 (the online shapes: CoST-GCN and "
          "CoAGCN, 1024 streams, 4-frame cycles); separate passes for SQ counters, FETCH_SIZE and WRITE_SIZE", ""]
     stage_entries = []
@@ -74,7 +74,7 @@ def main(tag, out_tag):
         for k in sorted(sq, key=lambda kk: -sum(dur[kk])):
             c = sq[k]
             g = sum(c.get("GRBM_GUI_ACTIVE", [0])) / 8
-            if g == 0 or ("stage" not in k and "agcn" not in k and not (mode.startswith("online") and ("step" in k or "co_" in k))):
+            if g == 0 or ("stage" not in k and "agcn" not in k and not (mode.startswith("online") and ("step" in k or "co_" in k or "gcn16" in k))):
                 continue
             wc = sum(c["SQ_WAVE_CYCLES"])
             secs = sum(dur[k]) / 1e3
@@ -87,16 +87,16 @@ def main(tag, out_tag):
                      f"{wc * 4 / (g * 1024):.2f} | {sum(c['SQ_WAIT_ANY']) / wc:.3f} | {sum(c['SQ_WAIT_INST_ANY']) / wc:.3f} | {rd:.1f} | {wr:.1f} |")
         L.append("")
         if mode == "online_costgcn":
-            dom = [v for k, v in traffic.items() if k.startswith("tcn_step_kernel")]
+            dom = [v for k, v in traffic.items() if k.startswith("tcn_step16_kernel") or k.startswith("tcn_step_kernel")]
             red = traffic.get("step_reduce_kernel")
             if dom and all(v["read_MB"] == v["read_MB"] for v in dom):
                 n = sum(v["launches"] for v in dom)
                 tot = sum((v["read_MB"] + v["write_MB"]) * 1e6 * v["launches"] for v in dom)
                 if red and red["read_MB"] == red["read_MB"]:
                     tot += (red["read_MB"] + red["write_MB"]) * 1e6 * red["launches"]      # the split-K launches' reduction
-                json.dump({"kernel": "tcn_step_kernel", "hbm_bytes_per_launch": tot / n, "launches": n, "source": f"profiles/{out_tag}_pmc_summary.md",
+                json.dump({"kernel": "tcn_step16_kernel", "hbm_bytes_per_launch": tot / n, "launches": n, "source": f"profiles/{out_tag}_pmc_summary.md",
                            "streams": 1024, "stream_shards": 1, "frames_per_launch": 4,
-                           "note": "average over the tcn_step_kernel launches of blocks 5-10 (split-K launches include their step_reduce_kernel)"},
+                           "note": "average over the stand-alone temporal-step launches of a cycle (block 1 and blocks 5-10; blocks 2-4 run inside co_stack16_kernel)"},
                           open(os.path.join(ROOT, "profiles", "traffic_tcn_step.json"), "w"), indent=1)
         if mode in ("f32", "f32_b1024"):
             dom = [v for k, v in traffic.items() if k.startswith("tcn_stage_kernel")]
