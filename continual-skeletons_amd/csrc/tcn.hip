@@ -18,26 +18,11 @@
 #include <type_traits>
 
 #include "mfma_core.h"
+#include "tcn_params.h"
 
 // ------------------------------------------------------------------------------------------------
 // TCN stage
 // ------------------------------------------------------------------------------------------------
-struct TcnParams {
-    const float *y, *w, *xres, *wres, *bias;
-    float *out;
-    int C, Cpad, Cout, Mpad, Tin, Tout, V, K, stride, pad;
-    int res_mode, Cres, CresPad, Tres, res_off, relu, ldb;
-    unsigned vmagic, mtiles, qtiles;
-    int nt;                       // positions per tile actually used (<= 16384 / MT)
-    int fast_epi;                 // row strides fit the 32-bit lane offsets of the scalar-base epilogue addressing
-    int prio;                     // raise wave priority inside MFMA segments (diagnostic CSK_NOPRIO=1 turns it off)
-    int vec_stage;                // 16-byte activation staging on interior tiles (diagnostic CSK_TCN_NOVEC=1 turns it off)
-    int no_peel_ct;
-    int ldb2;                     // conv-residual phase: LDS row stride of its activation tile
-    int ksplit, cper;             // split-K form (csk_tcn_stage_splitk_f32): ksplit channel ranges of cper channels per tile,
-    float *part;                  // raw partial sums part[(seg * ksplit + ks)][Cout][Tout * V]; ksplit == 1: off
-    unsigned long long *stamps;   // diagnostic (env CSK_STAMPS=<device ptr>): s_memtime stamps per workgroup, see tools/stamp_probe.py
-};
 
 // VT: joints per frame as a compile-time constant (25 / 18: the tap shift of an LDS read becomes an immediate offset), 0 = run time
 template <int MT, int NJ, bool K9 = false, bool SPLIT = false, int VT = 0>
@@ -416,6 +401,11 @@ static int tcn_stage_impl(const float *y, const float *w, const float *x_res, co
     // (the 64-row kernel stages 14 sweeps: at V = 64, stride 2 it keeps 128 of its 256 columns where the 128-row kernel
     // keeps 1 of 128) and the better MFMA-column utilisation wins; a shape that loses more than half the columns either
     // way says so once on stderr.
+    // the 16x16x4 tile family (tcn16.hip) for the shapes it is built for; bitwise the same sums (-2: not taken)
+    if (p.ksplit == 1) {
+        const int rc = csk_launch_tcn_stage16(p, n_seg, stream);
+        if (rc != -2) return rc;
+    }
     auto narrow = [&](int NT_, int nj_max_, int *ldb_) {
         int nt = NT_;
         for (;;) {

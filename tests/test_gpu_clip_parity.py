@@ -157,6 +157,36 @@ def test_general_gcn_kernel_matches_sparse_fast_path():
     check_parity(outs[0], outs[1], tol=1e-5, note="general vs sparse GCN kernel")
 
 
+def test_tile_families_are_bitwise_interchangeable():
+    """The 16x16x4 tile family (csrc/tcn16.hip, csrc/step16.hip:gcn16_kernel) stands in for the 32x32x2 kernels where a launch
+    shape favours it, on the claim that both walk the K loop in the same (chunk, tap / subset, channel) order and that
+    v_mfma_f32_16x16x4_f32 is the same fmaf chain: stride-1 blocks (identity and conv residual, 64 and 128 channels) and a
+    step-layout graph conv must come out BIT FOR BIT the same with the family forced on everywhere (CSK_TCN16=2, CSK_GCN16=2)
+    and switched off (=1).  (The stride-2 temporal conv of the family walks 4-channel chunks -- another fp32 order -- and is
+    compared with the oracle like every kernel.)  Subprocesses: the switches are read when the library is loaded."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); import _bootstrap, bench; pkg = _bootstrap.load(); A = pkg.ntu_graph().A; outs = [];\n"
+        "for (ci, co, res) in [(64, 64, True), (128, 128, True), (8, 64, True), (64, 64, False)]:\n"
+        "    b = pkg.SpatioTemporalBlock(ci, co, A, stride=1, residual=res).eval(); bench.randomise_(b, 3); b = b.to('cuda:0')\n"
+        "    x = torch.rand((3, ci, 45, 25), generator=torch.Generator().manual_seed(5)).to('cuda:0'); outs.append(b(x).cpu())\n"
+        "g = pkg.GraphConvolution(64, 64, A).eval(); bench.randomise_(g, 4); g = g.to('cuda:0')\n"
+        "P = 16 * 25; xs = torch.rand((4, 64, P), generator=torch.Generator().manual_seed(6)).to('cuda:0'); ys = torch.empty((4, 64, P), device='cuda:0')\n"
+        "g.stage(xs, ys, n_seg=4, frames=16, x_strides=(64 * P, P), y_strides=(64 * P, P)); outs.append(ys.cpu()); torch.save(outs, sys.argv[1])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for mode in ("2", "1"):
+        path = f"/tmp/tile16_{mode}.pt"
+        env = dict(os.environ, CSK_DIAG="1", CSK_TCN16=mode, CSK_GCN16=mode)
+        subprocess.check_call([sys.executable, "-c", code, path], env=env)
+        res.append(torch.load(path))
+    assert len(res[0]) == len(res[1]) == 5
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_) and bool(torch.isfinite(a_).all())
+
+
 def test_clip_forward_is_graph_capturable():
     """include/cskel.h promises launches without allocation or synchronisation: a whole 10-block forward must be
     capturable into a hipGraph and replay bit-identically."""
