@@ -342,41 +342,3 @@ __device__ __forceinline__ void mfma_taps_ct(const float *__restrict__ Wl, const
         }
     }
 }
-
-// The same with the lookahead bounded by hand: the fragment reads of tap r + 1 are issued in front of the 16 MFMAs of tap r
-// (operands double-buffered in registers, one scheduling fence per tap).  For callers whose LDS strides are compile-time
-// constants (the step kernels): there every read of mfma_taps_ct has an immediate offset, the compiler hoists all 48 of a
-// segment to its top and the kernel spills.
-template <int MT, int NTAPS>
-__device__ __forceinline__ void mfma_taps_pipe(const float *__restrict__ Wl, const float *__restrict__ Bl, int r0, int ldb, int tapB,
-                                               int offA, int off0, int off1, int kh, f32x16 (&acc)[2][2]) {
-    const float *wr = Wl + r0 * (KC * MT) + offA + kh * MT;
-    const float *br = Bl + r0 * tapB + kh * ldb;
-    float a[2][KC / 2][2], b[2][KC / 2][2];
-#pragma unroll
-    for (int s = 0; s < KC / 2; ++s) {
-        a[0][s][0] = wr[2 * s * MT]; a[0][s][1] = wr[2 * s * MT + 32];
-        b[0][s][0] = br[2 * s * ldb + off0]; b[0][s][1] = br[2 * s * ldb + off1];
-    }
-#pragma unroll
-    for (int r = 0; r < NTAPS; ++r) {
-        if (r + 1 < NTAPS) {
-#pragma unroll
-            for (int s = 0; s < KC / 2; ++s) {
-                a[(r + 1) & 1][s][0] = wr[(r + 1) * (KC * MT) + 2 * s * MT];
-                a[(r + 1) & 1][s][1] = wr[(r + 1) * (KC * MT) + 2 * s * MT + 32];
-                b[(r + 1) & 1][s][0] = br[(r + 1) * tapB + 2 * s * ldb + off0];
-                b[(r + 1) & 1][s][1] = br[(r + 1) * tapB + 2 * s * ldb + off1];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][0], b[r & 1][s][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][0], b[r & 1][s][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][1], b[r & 1][s][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r & 1][s][1], b[r & 1][s][1], acc[1][1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-

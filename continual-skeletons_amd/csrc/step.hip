@@ -150,7 +150,7 @@ __device__ __forceinline__ void tcn_step_tile(const StepParams &p, const int bx,
         rs.window(first, 1, p.slots, nwin, p.C, P);
         rs.issue(rbase, Cl, P, 0);
         const int t1 = (p.K + 2) / 3, t2 = min(p.K, 2 * t1);
-        constexpr bool k9 = K9;                          // 9 taps: straight-line 3-tap MFMA segments, reads one tap ahead (mfma_taps_pipe)
+        constexpr bool k9 = K9;                          // 9 taps: straight-line 3-tap MFMA segments (mfma_taps_ct; spill-free at 155-236 VGPRs, kernel_resources.txt)
         int c0 = 0;
         for (; c0 + KC < CpadL; c0 += KC) {
             __syncthreads();

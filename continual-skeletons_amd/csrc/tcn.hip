@@ -470,8 +470,15 @@ static int tcn_stage_impl(const float *y, const float *w, const float *x_res, co
             kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true, false, 18> : tcn_stage_kernel<128, 9, true, false, 18>)
                        : (nj <= 6 ? tcn_stage_kernel<64, 6, true, false, 18> : tcn_stage_kernel<64, 9, true, false, 18>);
     }
+    if (p.ksplit > 1 && (nj > 9 || n_seg > 65535)) {
+        // the split-K instantiations stage <= 576 positions per channel and their reduction has the segment in grid.y: a request
+        // outside that (a stride-2 64-row tile at V = 18: 702 positions; > 65 535 sequences) runs the plain kernel -- one
+        // workgroup per tile walks the whole K loop, same result up to summation order, no partial sums, no reduction launch
+        p.ksplit = 1;
+        p.cper = p.Cpad;
+        grid = dim3(p.qtiles * p.mtiles * n_seg);
+    }
     if (p.ksplit > 1) {
-        if (nj > 9) CSK_FAIL("tcn_stage: the split-K form covers activation tiles of <= 576 positions per channel");
         kern = big ? (nj <= 6 ? tcn_stage_kernel<128, 6, true, true> : tcn_stage_kernel<128, 9, true, true>)
                    : (nj <= 6 ? tcn_stage_kernel<64, 6, true, true> : tcn_stage_kernel<64, 9, true, true>);
     }

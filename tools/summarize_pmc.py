@@ -21,7 +21,7 @@ def rows_of(pattern):
 
 
 def short(name):
-    for k in ("co_stack16_kernel", "tcn_step16_kernel", "gcn16_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
+    for k in ("co_stack16_kernel", "tcn_step16_kernel", "tcn_stage16_kernel", "gcn16_kernel", "tcn_split_stage_kernel", "gcn_split_stage_kernel", "tcn_stage_kernel", "gcn_stage_sparse2_kernel", "gcn_stage_dense2_kernel", "gcn_stage_dense_kernel", "gcn_stage_kernel",
               "agcn_embed_attention_kernel", "agcn_softmax_parts_kernel", "tcn_step_kernel", "co_block_kernel", "step_reduce_kernel", "co_head_kernel",
               "agcn_logits_partial_kernel", "agcn_softmax_kernel", "input_norm_kernel", "pool_kernel", "fc_kernel"):
         if k in name:
@@ -99,11 +99,11 @@ def main(tag, out_tag):
                            "note": "average over the stand-alone temporal-step launches of a cycle (block 1 and blocks 5-10; blocks 2-4 run inside co_stack16_kernel)"},
                           open(os.path.join(ROOT, "profiles", "traffic_tcn_step.json"), "w"), indent=1)
         if mode in ("f32", "f32_b1024"):
-            dom = [v for k, v in traffic.items() if k.startswith("tcn_stage_kernel")]
+            dom = [v for k, v in traffic.items() if k.startswith("tcn_stage_kernel") or k.startswith("tcn_stage16_kernel")]
             if dom and all(v["read_MB"] == v["read_MB"] for v in dom):
                 n = sum(v["launches"] for v in dom)
                 hb = sum((v["read_MB"] + v["write_MB"]) * 1e6 * v["launches"] for v in dom) / n
-                stage_entries.append({"kernel": "tcn_stage_kernel", "hbm_bytes_per_launch": hb, "launches": n,
+                stage_entries.append({"kernel": "tcn_stage_kernel + tcn_stage16_kernel", "hbm_bytes_per_launch": hb, "launches": n,
                                       "source": f"profiles/{out_tag}_pmc_summary.md", "batch": batch})
                 # one entry per profiled batch size (bench.py: load_traffic(batch=...)); the batch-256 entry stays at the top level too
                 top = next((e for e in stage_entries if e["batch"] == 256), stage_entries[0])
