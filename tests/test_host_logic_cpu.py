@@ -566,3 +566,54 @@ def test_folded_operand_cache_sees_every_kind_of_weight_edit():
     with torch.no_grad():
         net.data_bn.running_mean.add_(1.0)
     assert net._packed_ops("cpu") is not n0
+
+
+def test_co_stack_step_argument_errors_and_host_side_policies():
+    """csk_co_stack_step_f32 (a run of blocks in one launch) validates the chain before any launch: block i + 1 must read what
+    block i emits.  CoStGcn.set_max_cycle / SplitScratch: host-side logic that needs no GPU."""
+    import ctypes as C
+    import torch
+    pkg = _bootstrap.load()
+    lib = pkg.native.lib()
+
+    class Args(C.Structure):
+        _fields_ = [("xin", C.c_void_p), ("xin_slots", C.c_int32), ("xin_slot0", C.c_int32), ("c_in", C.c_int32),
+                    ("gcn_w", C.c_void_p), ("gcn_bias", C.c_void_p), ("ell_src", C.c_void_p), ("ell_val", C.c_void_p),
+                    ("ell_cnt", C.c_int32 * 3), ("ell_w", C.c_int32), ("gcn_res_mode", C.c_int32), ("y_ring", C.c_void_p),
+                    ("y_slots", C.c_int32), ("y_slot0", C.c_int32), ("tcn_w", C.c_void_p), ("tcn_bias", C.c_void_p),
+                    ("res_mode", C.c_int32), ("x_res_slot0", C.c_int32), ("out", C.c_void_p), ("out_slots", C.c_int32),
+                    ("out_slot0", C.c_int32), ("c_out", C.c_int32)]
+    blocks = (Args * 2)()
+    for i, b in enumerate(blocks):
+        b.xin, b.xin_slots, b.xin_slot0, b.c_in = 0x1000 * (i + 1), 12, 3, 64
+        for f in ("gcn_w", "gcn_bias", "ell_src", "ell_val", "tcn_w", "tcn_bias"):
+            setattr(b, f, 0x9000)
+        b.ell_cnt[0], b.ell_cnt[1], b.ell_cnt[2], b.ell_w, b.gcn_res_mode = 1, 1, 4, 4, 1
+        b.y_ring, b.y_slots, b.y_slot0, b.res_mode, b.x_res_slot0 = 0x5000 * (i + 1), 16, 3, 1, 11
+        b.out, b.out_slots, b.out_slot0, b.c_out = 0x1000 * (i + 2), 12, 3, 64
+    call = lambda n: lib.csk_co_stack_step_f32(n, C.byref(blocks), 8, 25, 200, None)
+    assert call(0) == -1 and b"blocks expected" in lib.csk_last_error()
+    assert call(5) == -1 and b"blocks expected" in lib.csk_last_error()
+    blocks[1].xin_slot0 = 4                      # block 1 would read a slot block 0 does not write this cycle
+    assert call(2) == -1 and b"does not read what block 0 emits" in lib.csk_last_error()
+    blocks[1].xin_slot0, blocks[1].c_in = 3, 32
+    assert call(2) == -1 and b"does not read what block 0 emits" in lib.csk_last_error()
+    # set_max_cycle: range check, re-bind on change
+    net = pkg.CoStGcn(pkg.ntu_graph().A).eval()
+    assert net.max_cycle == 8
+    net._n = 5
+    net.set_max_cycle(4)
+    assert net.max_cycle == 4 and net._n is None
+    for bad in (0, 9, 2.5):
+        with pytest.raises(ValueError):
+            net.set_max_cycle(bad)
+    # SplitScratch: one buffer per (device, stream), superseded buffers stay alive until release()
+    from continual_skeletons_amd import blocks as blk
+    sc = blk.SplitScratch()
+    assert sc.nbytes() == 0
+    m = pkg.StGcn(pkg.ntu_graph().A).eval()
+    pkg.set_clip_latency_mode(m, 4)
+    shared = {id(mod.__dict__["_split_scratch"]) for mod in m.modules() if "_split_scratch" in mod.__dict__}
+    assert len(shared) == 1                      # one scratch for the whole tree
+    pkg.set_clip_latency_mode(m, 0)
+    assert all(mod.__dict__.get("_split_scratch") is None for mod in m.modules() if "_split_scratch" in mod.__dict__)
