@@ -84,6 +84,14 @@ __device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, co
         if (TAIL && KCH > p.C) rs.issue_tail(rbase, 0, p.C, P, tid);
         else rs.issue(rbase);
         if (p.stamps) st1 = tq = __builtin_amdgcn_s_memtime();
+        // Issue priority inside the MFMA segments.  The two workgroups of a CU do identical work; at EQUAL priority the
+        // arbiter prefers the older wave: the workgroup that started ~400 cycles earlier runs 22 % ahead, finishes, and its
+        // partner walks the rest of its K loop alone -- bound by its own LDS round trips (stamps, 256-channel launch: 951 k
+        // against 1 215 k cycles in EVERY CU).  So the favoured workgroup alternates chunk by chunk (priority 2 against 1):
+        // 1 058 k / 1 153 k, the launch 4.6 % shorter.  p.stagger >> 16 (CSK_TCN16_PRIO under CSK_DIAG=1): 0 = equal
+        // priorities, 1 = alternating, 2 = always the younger workgroup.
+        const int pmode = p.stagger >> 16;
+        int turn = pmode == 0 ? 0 : (int)(__builtin_amdgcn_s_getreg(6148) & 1);   // HW_ID wave slot: 0 = the older workgroup of the CU
         for (int c0 = 0; c0 < p.Cpad; c0 += KCH) {
             __syncthreads();
             if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
@@ -98,20 +106,17 @@ __device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, co
             const bool tail = TAIL && cn + KCH > p.C;                           // uniform
             ws.issue_one(0, wnext);
             if (!tail) rs.template issue_third<0>(rnext);
-            __builtin_amdgcn_s_setprio(1);
+            if (turn & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+            turn += pmode & 1;
 #pragma unroll
             for (int r = 0; r < 3; ++r) mfma16_tap<NB>(wl_lane + r * KCH * LDW, bl_lane + G::slot_lds(r), acc);
-            __builtin_amdgcn_s_setprio(0);
             ws.issue_one(1, wnext);
             if (!tail) rs.template issue_third<1>(rnext);
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int r = 3; r < 6; ++r) mfma16_tap<NB>(wl_lane + r * KCH * LDW, bl_lane + G::slot_lds(r), acc);
-            __builtin_amdgcn_s_setprio(0);
             ws.issue_one(2, wnext);
             if (!tail) rs.template issue_third<2>(rnext);
             else rs.issue_tail(rnext, cn, p.C, P, tid);
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int r = 6; r < 9; ++r) mfma16_tap<NB>(wl_lane + r * KCH * LDW, bl_lane + G::slot_lds(r), acc);
             __builtin_amdgcn_s_setprio(0);
@@ -168,7 +173,7 @@ __device__ __forceinline__ void tcn16_tile(const StepParams &p, const int bx, co
 template <int NB, int E, int HS, bool TAIL>
 __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    stagger_odd_slot(p.stagger);
+    stagger_odd_slot(p.stagger & 0xffff);
     // XCD-contiguous work order, m-tile fastest (the m-tiles of a position tile read the same ring window)
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
     tcn16_tile<NB, E, HS, TAIL>(p, (int)(wid / (p.gy * p.gz)), (int)(wid % p.gy), (int)((wid / p.gy) % p.gz), smem);
@@ -247,6 +252,7 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     xs.commit(Xs);
     issue_x(1);
     __syncthreads();
+    const int gmode = (p.stagger >> 20) & 7, godd = (int)(__builtin_amdgcn_s_getreg(6148) & 1);   // HW_ID wave slot: 0 = the older workgroup
     unsigned long long gp0 = 0, gp1 = 0, gp2 = 0, gp3 = 0, gp4 = 0, gq = 0, gst0 = 0;   // diagnostic phase sums (p.stamps only)
     if (p.stamps) gst0 = gq = __builtin_amdgcn_s_memtime();
     for (int c = 0; c < nchunks; ++c) {
@@ -300,7 +306,9 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
         xs.commit(Xs);
         issue_x(c + 2);
         if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp2 += t - gq; gq = t; }
-        __builtin_amdgcn_s_setprio(1);
+        // (issue priority of the MFMA phase: see tcn16_tile -- mode 1 / 2: the favoured workgroup of the CU alternates chunk by chunk)
+        if (gmode == 0) __builtin_amdgcn_s_setprio(1);
+        else if (gmode != 4) { if (((gmode == 3 ? 0 : c) + godd) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
         if (!(p.stagger & 0x20000)) {                          // (diagnostic: CSK_GCN16_SKIP=2: without its MFMA phase)
 #pragma unroll
         for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
@@ -365,7 +373,7 @@ __device__ __forceinline__ void stage_handoff() {
 template <int NB>
 __global__ __launch_bounds__(NTHREADS, 2) void co_stack16_kernel(const CoStackParams sp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    stagger_odd_slot(sp.b[0].g.stagger);
+    stagger_odd_slot(sp.b[0].g.stagger & 0xffff);
     const int bx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
     for (int i = 0; i < sp.nblk; ++i) {
         const CoStackBlock &b = sp.b[i];
@@ -385,7 +393,7 @@ int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
     const int64_t grid = (int64_t)p.qtiles * p.mtiles * (n_seg / F);
     if (grid >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
     void (*kern)(GcnParams) = p.R == 4 ? gcn16_kernel<NB, F, true> : gcn16_kernel<NB, F, false>;
-    p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER) | (csk_diag_int("CSK_GCN16_SKIP") << 16);
+    p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER) | ((csk_diag_int("CSK_GCN16_SKIP") & 15) << 16) | (prio_mode("CSK_GCN16_PRIO", GCN16_PRIO) << 20);
     p.stamps = csk_diag_stamps();
     const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 8 * NT) * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
@@ -399,7 +407,7 @@ int launch16(StepParams p, int n_emit, hipStream_t s) {
     p.gx = (unsigned)((p.P + G::NP - 1) / G::NP); p.gy = (unsigned)(p.Mpad / 64); p.gz = (unsigned)(n_emit / E);
     if ((int64_t)p.gx * p.gy * p.gz >= (1ll << 31)) CSK_FAIL("tcn_step: grid too large");
     const bool tail = (p.C % G::KCH) != 0 || (p.res_mode == CSK_RES_CONV && (p.Cres % G::KR) != 0);
-    p.stagger = stagger_units("CSK_TCN16_STAGGER", TCN16_STAGGER);
+    p.stagger = stagger_units("CSK_TCN16_STAGGER", TCN16_STAGGER) | (prio_mode("CSK_TCN16_PRIO", TCN16_PRIO) << 16);
     p.stamps = csk_diag_stamps();
     void (*kern)(StepParams) = tail ? tcn_step16_kernel<NB, E, HS, true> : tcn_step16_kernel<NB, E, HS, false>;
     const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
@@ -511,7 +519,7 @@ int csk_launch_co_stack16(int n_blocks, const csk_co_block_args *b, int n_skel, 
         g.frames = n_skel; g.V = V; g.R = a.gcn_res_mode == CSK_RES_CONV ? 4 : 3; g.res_mode = a.gcn_res_mode;
         g.vmagic = vmagic_of(V); g.mtiles = 1; g.qtiles = (unsigned)((Q + NP - 1) / NP); g.ksplit = 1; g.cper = g.CinPad; g.part = nullptr;
         g.x_ring_slots = a.xin_slots; g.x_ring_slot0 = a.xin_slot0; g.y_ring_slots = a.y_slots; g.y_ring_slot0 = a.y_slot0;
-        g.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER);
+        g.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER) | (prio_mode("CSK_GCN16_PRIO", GCN16_PRIO) << 20);
         g.stamps = nullptr;
         StepParams &t = sp.b[i].t;
         t = StepParams{};
@@ -520,7 +528,7 @@ int csk_launch_co_stack16(int n_blocks, const csk_co_block_args *b, int n_skel, 
         t.K = 9; t.slots = a.y_slots; t.head = a.y_slot0; t.head_step = 1; t.res_mode = a.res_mode;
         t.Cres = a.res_mode ? a.c_in : 1; t.CresPad = round_up(t.Cres, CSK_CPAD); t.relu = 1; t.P = P; t.fast_epi = 1;
         t.xres_slots = a.xin_slots; t.xres_slot0 = a.x_res_slot0; t.xres_step = 1; t.out_slots = a.out_slots; t.out_slot0 = a.out_slot0;
-        t.stamps = nullptr;
+        t.stamps = nullptr; t.stagger = prio_mode("CSK_TCN16_PRIO", TCN16_PRIO) << 16;
         t.ksplit = 1; t.cper = t.Cpad; t.part = nullptr; t.gx = (unsigned)((P + NP - 1) / NP); t.gy = 1; t.gz = 1;
     }
     void (*kern)(CoStackParams) = best_nb == 25 ? co_stack16_kernel<25> : co_stack16_kernel<18>;

@@ -285,12 +285,14 @@ int launch_stage16(TcnParams p, int n_seg, hipStream_t s) {
 // wins where the K loop is short -- C = 64: 2.282 vs 2.380 ms (-4.1 %); C = 128, stride 2: 4.853 vs 4.923 (-1.4 %) -- ties at
 // C = 128, stride 1 and loses 1.8 % / 0.5 % at C = 256 (stride 2 / 1): both families end at 0.80-0.83 of the fp32 MFMA peak on long
 // K loops (two waves per SIMD, each bound by the LDS round trip of its operand reads while its partner is outside its MFMA
-// segment).  Taken for C <= 64 and for stride 2 at C <= 128.
+// segment).  Taken for C <= 64 and for stride 2 at C <= 128.  V = 18 (Kinetics): every layer -- 16 frames are 288 = 18 x 16 columns
+// exactly where the 32-wide tiles hold 180 of 192 (A-GCN clip forward, batch 64, same process: 16.74 -> 16.53 ms; C = 128 stride 1
+// 0.893 -> 0.837 ms, C = 256 stride 1 1.756 -> 1.672, C = 256 stride 2 1.897 -> 1.879).
 // CSK_TCN16 under CSK_DIAG=1: 1 = never, 2 = every shape the kernel supports (A/B runs, parity tests of the wide layers).
 int csk_launch_tcn_stage16(TcnParams p, int n_seg, void *stream) {
     const int mode = csk_diag_int("CSK_TCN16");
     if (mode == 1) return -2;
-    if (mode != 2 && p.C > (p.stride == 2 ? 128 : 64)) return -2;
+    if (mode != 2 && p.V != 18 && p.C > (p.stride == 2 ? 128 : 64)) return -2;
     if (p.K != 9 || p.ksplit != 1 || (p.V != 25 && p.V != 18) || p.stride < 1 || p.stride > 2) return -2;
     if ((p.pad * p.V) & 3) return -2;                            // the staged window starts on a 16-byte LDS boundary
     if (p.C % 8 != 0 || p.C < 8) return -2;                      // whole chunks of real channels (the stack's convs: 64 / 128 / 256)

@@ -18,6 +18,14 @@ inline int stagger_units(const char *env, int dflt) {
     const int v = csk_diag_int(env);
     return v > 0 ? v - 1 : dflt;
 }
+// which workgroup of a CU the issue arbiter favours inside the MFMA segments (step16.hip, tcn16_tile / gcn16_tile): 0 = equal
+// priorities (= the older one, always), 1 = alternating chunk by chunk, 2 = always the younger one; CSK_*_PRIO under CSK_DIAG=1
+// overrides (value + 1).  Round 6, 1024 NTU streams, same process: 985 -> 1 004 k frames/s (temporal step) -> 1 011 k (+ graph conv).
+constexpr int TCN16_PRIO = 1, GCN16_PRIO = 1;
+inline int prio_mode(const char *env, int dflt) {
+    const int v = csk_diag_int(env);
+    return v > 0 ? v - 1 : dflt;
+}
 inline double cost_model(int64_t tiles64, double tile_cols) { return (double)((tiles64 + CUS - 1) / CUS) * tile_cols; }
 
 constexpr int imax(int a, int b) { return a > b ? a : b; }

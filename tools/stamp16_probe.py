@@ -36,6 +36,29 @@ for (c, n_emit, hs, res) in [(64, 4, 1, 1), (64, 4, 1, 0), (128, 2, 1, 1), (256,
     print(f"STAMP16 C={c} n_emit={n_emit} res={res}: span {span} ticks | per wave: prologue {np.median(pro):.0f} loop {np.median(loop):.0f} epilogue {np.median(epi):.0f} "
           f"| per chunk: barrier1 wait {np.median(st[:, :, 4]) / chunks:.0f}  commit+barrier2 {np.median(st[:, :, 5]) / chunks:.0f}  mfma+issue {np.median(st[:, :, 6]) / chunks:.0f} "
           f"(225 MFMAs = 7200 cycles alone, 14400 shared) | start spread {np.percentile(st[:, :, 0], 99) - st[:, :, 0].min():.0f} | end spread {st[:, :, 3].max() - np.percentile(st[:, :, 3], 1):.0f}")
+    # per workgroup: start (first wave in) and end (last wave out) relative to the launch's first stamp, and its duration
+    t0 = st[:, :, 0].min()
+    ws, we = st[:, :, 0].min(axis=1) - t0, st[:, :, 3].max(axis=1) - t0
+    pc = lambda a: " / ".join(f"{np.percentile(a, q):.0f}" for q in (1, 25, 50, 75, 99, 100))
+    print(f"STAMP16   workgroups (p1 / p25 / p50 / p75 / p99 / max): start {pc(ws)} | end {pc(we)} | duration {pc(we - ws)}")
+    # who shares a CU: s_memtime has a different base per XCD (the start stamps fall into 8 clusters); HW_ID bits 8-15 = CU / SH / SE
+    order = np.argsort(ws); gaps = np.diff(ws[order]); cuts = np.where(gaps > 10_000_000)[0]
+    xcd = np.zeros(nwg, dtype=int); xcd[order] = np.searchsorted(cuts, np.arange(nwg), side="left")
+    cu = (st[:, 0, 7] >> 8) & 0xFF
+    simd0 = (st[:, 0, 7] >> 4) & 3
+    dur = we - ws
+    pairs = {}
+    for w in range(nwg):
+        pairs.setdefault((int(xcd[w]), int(cu[w])), []).append(w)
+    two = [v for v in pairs.values() if len(v) == 2]
+    if two:
+        d = np.array([[dur[a], dur[b]] for a, b in two]); st_d = np.array([[ws[a], ws[b]] for a, b in two])
+        first_is_fast = np.mean((st_d[:, 0] < st_d[:, 1]) == (d[:, 0] < d[:, 1]))
+        print(f"STAMP16   {len(pairs)} CUs seen over {len(cuts) + 1} XCD clusters, {len(two)} hold two workgroups: |duration difference| inside a CU median {np.median(np.abs(d[:, 0] - d[:, 1])):.0f}, "
+              f"faster one median {np.median(d.min(axis=1)):.0f}, slower one {np.median(d.max(axis=1)):.0f}; the one that started first is the faster one in {first_is_fast:.2f} of the CUs; "
+              f"start offset inside a CU median {np.median(np.abs(st_d[:, 0] - st_d[:, 1])):.0f}; per-XCD median duration {[int(np.median(dur[xcd == k])) for k in range(len(cuts) + 1)]}")
+        others = [len(v) for v in pairs.values() if len(v) != 2]
+        if others: print(f"STAMP16   CUs with another count: {np.bincount(others)}")
 
 # graph conv (gcn16_kernel): phase sums per wave and chunk of 8 channels
 A = pkg.ntu_graph().A
