@@ -146,12 +146,35 @@ __device__ __forceinline__ void stagger_odd_slot(int units) {
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(1);
 }
 
+// Operand reads AHEAD of their use.  Left to itself the scheduler emits `ds_read2_b32; s_waitcnt lgkmcnt(0); mfma; mfma` 13
+// times per tap: every MFMA pair waits for the LDS round trip of the read issued right in front of it, and a wave that has
+// the matrix pipe to itself (its SIMD partner in a barrier / commit phase, or gone) runs at ~56 cycles per 32-cycle MFMA.
+// The group barriers below order a straight-line run of NM MFMAs and their reads as: 1 + CSK_READ_AHEAD reads, then (two
+// MFMAs, one read) over and over -- the read of pair i + CSK_READ_AHEAD is in flight under pair i.  Round 6, 1024 NTU
+// streams, same box: 1 009 k -> 1 035 k frames/s at 2 (1: 997 k; 3: 1 034 k; one schedule per 3-tap segment instead of per tap:
+// 1 021 k).  The clip kernels (many rounds per launch, the partner rarely away) measured no change with the same hints.
+#ifndef CSK_READ_AHEAD
+#define CSK_READ_AHEAD 2
+#endif
+template <int NM>
+__device__ __forceinline__ void mfma16_read_ahead() {
+#if CSK_READ_AHEAD > 0
+    __builtin_amdgcn_sched_group_barrier(0x100, 1 + CSK_READ_AHEAD, 0);   // DS reads: the weight fragment + the first activation pairs
+#pragma unroll
+    for (int i = 0; i < (NM + 1) / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                // two MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                // one DS read
+    }
+#endif
+}
+
 // one tap (one k-step of 4 channels): acc[cb] += act[16 cb .. + 15][k] x w[k][16 channels]
 template <int NB>
 __device__ __forceinline__ void mfma16_tap(const float *__restrict__ wl, const float *__restrict__ bl, f32x4 (&acc)[NB]) {
     const float wf = wl[0];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bl[16 * cb], wf, acc[cb], 0, 0, 0);
+    mfma16_read_ahead<NB>();
 }
 
 // Epilogue shared by the kernels of this file: out = [ReLU](acc + bias + identity residual).  A lane holds positions
