@@ -194,11 +194,17 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(cons
 // count that is not a multiple of 8: the chunk holding the last real channels re-reads the last real row for the rows past it,
 // chunks of padding only re-read that chunk (their packed weights are zero; the value only has to be finite -- the clamp of
 // gcn_stage_sparse2_kernel).
+#ifndef CSK_GCN_AHEAD
+#define CSK_GCN_AHEAD CSK_READ_AHEAD
+#endif
+constexpr int GCN_AHEAD = CSK_GCN_AHEAD;
 template <int NB, int F, bool CONVRES>
 __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, const int qt, const int sg, float *smem) {
     constexpr int R = CONVRES ? 4 : 3, KCG = 8, NE = KCG * R;
-    constexpr int NT = 16 * NB, NPG = NT / F, AROW = row16(NT), XROW = NT, LDW = 80;
-    constexpr int NCOL = (NT + NTHREADS - 1) / NTHREADS;               // columns aggregated per thread
+    constexpr int NT = 16 * NB, NPG = NT / F, AROW = row16(NT), LDW = 80;
+    typedef WinT16<F, NPG, true> XS;                                   // x rows staged channel-interleaved (tile16.h)
+    constexpr int XH = XS::HALF;
+    static_assert(NT % 2 == 0 && NT <= 2 * NTHREADS, "a thread aggregates two adjacent columns");
     static_assert(NT % F == 0 && NPG % 4 == 0, "a segment's positions are whole 16-byte quads");
     float *Wl = smem, *Ba = smem + NE * LDW, *Xs = Ba + NE * AROW;
     int tid_ = threadIdx.x;
@@ -208,31 +214,12 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     const int m0 = mt * 64, q0 = qt * NPG, seg0 = sg * F;
     const int V = p.V, Q = p.frames * V;
     const int nval = min(NPG, Q - q0);                                 // valid positions of the tile: whole skeletons
-    // adjacency entries of this thread's columns (offsets inside an x row of the tile)
-    int eoff[NCOL][6], ioff[NCOL], acol[NCOL];
-    float eval[NCOL][6];
-#pragma unroll
-    for (int n = 0; n < NCOL; ++n) {
-        const int col = min(n * NTHREADS + tid, NT - 1);
-        const int f = col / NPG, pos = min(col - f * NPG, nval - 1);
-        const int t = div_magic(pos, p.vmagic), w = pos - t * V, sb = f * NPG + t * V;
-        acol[n] = col;
-        ioff[n] = sb + w;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;          // subsets 0,1: one entry; subset 2: four
-            const bool have = k < p.ell_cnt[r];
-            const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
-            eoff[n][e] = sb + (have ? p.ell_src[idx] : 0);
-            eval[n][e] = have ? p.ell_val[idx] : 0.f;
-        }
-    }
     f32x4 acc[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     W16<R, KCG, LDW, true> ws;
-    Win16<KCG, F, NPG, XROW, false, true> xs;
+    XS xs;
     const int nfull = p.Cin / KCG, rem = p.Cin % KCG;                  // whole chunks, real channels of the partial one
     const int clast = rem ? nfull : nfull - 1;                         // last chunk with a real channel
     ws.setup(p.CinPad, p.Mpad, tid);
@@ -248,6 +235,28 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     };
     ws.issue(wbase);
     issue_x(0);
+    // (behind the first chunk's loads, whose latency covers the table reads)
+    // adjacency entries of this thread's two columns c0, c0 + 1 (offsets inside the interleaved x tile); threads past the tile
+    // redo its last pair (the same values to the same addresses), a wave with no column of its own skips the phase
+    int eoff[2][6], ioff[2];
+    float eval[2][6];
+    const int c0 = min(2 * tid, NT - 2);
+    const bool p1_wave = wave * 128 < NT;                              // (wave-uniform)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = c0 + n;
+        const int f = col / NPG, pos = min(col - f * NPG, nval - 1);
+        const int t = div_magic(pos, p.vmagic), w = pos - t * V, sb = f * NPG + t * V;
+        ioff[n] = xt_off(sb + w);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;          // subsets 0,1: one entry; subset 2: four
+            const bool have = k < p.ell_cnt[r];
+            const int idx = (r * V + w) * p.ell_w + min(k, p.ell_w - 1);
+            eoff[n][e] = xt_off(sb + (have ? p.ell_src[idx] : 0));
+            eval[n][e] = have ? p.ell_val[idx] : 0.f;
+        }
+    }
     __syncthreads();                                                   // (a previous phase of a fused launch may still read LDS)
     xs.commit(Xs);
     issue_x(1);
@@ -256,44 +265,42 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     unsigned long long gp0 = 0, gp1 = 0, gp2 = 0, gp3 = 0, gp4 = 0, gq = 0, gst0 = 0;   // diagnostic phase sums (p.stamps only)
     if (p.stamps) gst0 = gq = __builtin_amdgcn_s_memtime();
     for (int c = 0; c < nchunks; ++c) {
-        // ---- P1: aggregate chunk c, commit its weights, load the next chunk's.  Per column the 8 x 6 (+ 8) source values are
-        // read first, all in flight together (the aggregated rows and the x rows share LDS: interleaved with the writes the
-        // reads would be issued six at a time, each batch behind the previous one's latency)
-        if (!(p.stagger & 0x10000)) {                          // (diagnostic: CSK_GCN16_SKIP=1 times the kernel without its aggregation phase)
-        constexpr int KB = (CONVRES && NB > 20) ? 2 : 8;      // channels whose source values are in flight together (register budget)
+        // ---- P1: aggregate chunk c, commit its weights, load the next chunk's.  Four rounds (channel half h, column n): the six
+        // source joints of a column with 4 channels each in six 16-byte gathers from the channel-interleaved x tile (WinT16),
+        // multiplied out, the two columns of a thread written as pairs
+        if (!(p.stagger & 0x10000) && p1_wave) {               // (diagnostic: CSK_GCN16_SKIP=1 times the kernel without its aggregation phase)
 #pragma unroll
-        for (int n = 0; n < NCOL; ++n) {
+        for (int h = 0; h < 2; ++h) {                          // channels 4 h .. 4 h + 3 of the chunk
+            f32x2 res[4][3];
 #pragma unroll
-            for (int k0 = 0; k0 < KCG; k0 += KB) {
-                float xv[KB][6];
+            for (int n = 0; n < 2; ++n) {
+                // (the six 16-byte gathers of the NEXT round in flight under this round's arithmetic: 4.75 k -> 4.45 k cycles for
+                // the phase, which the partner's MFMA phase lost again -- 6.7 k -> 7.3 k: not kept)
+                f32x4 x[6];
 #pragma unroll
-                for (int kk = 0; kk < KB; ++kk) {
-                    const float *bx = Xs + (k0 + kk) * XROW;
-#pragma unroll
-                    for (int e = 0; e < 6; ++e) xv[kk][e] = bx[eoff[n][e]];
-                }
+                for (int e = 0; e < 6; ++e) x[e] = *reinterpret_cast<const f32x4 *>(Xs + h * XH + eoff[n][e]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < KB; ++kk) {
-                    const float b0 = eval[n][0] * xv[kk][0];
-                    const float b1 = eval[n][1] * xv[kk][1];
-                    float s2 = eval[n][2] * xv[kk][2];
-                    s2 = fmaf(eval[n][3], xv[kk][3], s2);
-                    s2 = fmaf(eval[n][4], xv[kk][4], s2);
-                    s2 = fmaf(eval[n][5], xv[kk][5], s2);
-                    Ba[gcn_entry(k0 + kk, 0, R) * AROW + acol[n]] = b0;
-                    Ba[gcn_entry(k0 + kk, 1, R) * AROW + acol[n]] = b1;
-                    Ba[gcn_entry(k0 + kk, 2, R) * AROW + acol[n]] = s2;
+                for (int kk = 0; kk < 4; ++kk) {
+                    res[kk][0][n] = eval[n][0] * x[0][kk];
+                    res[kk][1][n] = eval[n][1] * x[1][kk];
+                    float s2 = eval[n][2] * x[2][kk];
+                    s2 = fmaf(eval[n][3], x[3][kk], s2);
+                    s2 = fmaf(eval[n][4], x[4][kk], s2);
+                    s2 = fmaf(eval[n][5], x[5][kk], s2);
+                    res[kk][2][n] = s2;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) *reinterpret_cast<f32x2 *>(Ba + gcn_entry(4 * h + kk, r, R) * AROW + c0) = res[kk][r];
             if (CONVRES) {                                    // fourth "subset": the input itself (the conv gcn_residual's operand)
-                float xi[KCG];
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(Xs + h * XH + ioff[0]);
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(Xs + h * XH + ioff[1]);
 #pragma unroll
-                for (int kk = 0; kk < KCG; ++kk) xi[kk] = Xs[kk * XROW + ioff[n]];
-#pragma unroll
-                for (int kk = 0; kk < KCG; ++kk) Ba[gcn_entry(kk, 3, R) * AROW + acol[n]] = xi[kk];
-                __builtin_amdgcn_sched_barrier(0);
+                for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<f32x2 *>(Ba + gcn_entry(4 * h + kk, 3, R) * AROW + c0) = f32x2{x0[kk], x1[kk]};
             }
         }
         }
@@ -311,7 +318,7 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
         else if (gmode != 4) { if (((gmode == 3 ? 0 : c) + godd) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
         if (!(p.stagger & 0x20000)) {                          // (diagnostic: CSK_GCN16_SKIP=2: without its MFMA phase)
 #pragma unroll
-        for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
+        for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB, GCN_AHEAD>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
         }
         __builtin_amdgcn_s_setprio(0);
         if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp3 += t - gq; gq = t; }
@@ -343,7 +350,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn16_kernel(const GcnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     stagger_odd_slot(p.stagger & 0xffff);
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    unsigned long long k0 = 0;
+    if (p.stamps) k0 = __builtin_amdgcn_s_memtime();
     gcn16_tile<NB, F, CONVRES>(p, (int)(wid % p.mtiles), (int)((wid / p.mtiles) % p.qtiles), (int)(wid / (p.mtiles * p.qtiles)), smem);
+    if (p.stamps && (threadIdx.x & 63) == 0) {                 // diagnostic: workgroup start / end (stores retired), behind the per-wave records
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *o = p.stamps + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+        o[0] = k0; o[1] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,7 +409,7 @@ int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
     void (*kern)(GcnParams) = p.R == 4 ? gcn16_kernel<NB, F, true> : gcn16_kernel<NB, F, false>;
     p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER) | ((csk_diag_int("CSK_GCN16_SKIP") & 15) << 16) | (prio_mode("CSK_GCN16_PRIO", GCN16_PRIO) << 20);
     p.stamps = csk_diag_stamps();
-    const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 8 * NT) * sizeof(float);
+    const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 2 * WinT16<F, NPG>::HALF) * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, p);
     return (int)hipGetLastError();
@@ -533,7 +547,8 @@ int csk_launch_co_stack16(int n_blocks, const csk_co_block_args *b, int n_skel, 
     }
     void (*kern)(CoStackParams) = best_nb == 25 ? co_stack16_kernel<25> : co_stack16_kernel<18>;
     const int NT = 16 * best_nb;
-    const size_t lds_g = (size_t)(8 * 4 * (80 + row16(NT)) + 8 * NT), lds_t = best_nb == 25 ? G16<25, 4, 1>::LDS_FLOATS : G16<18, 4, 1>::LDS_FLOATS;
+    // (identity-residual graph convs only: R = 3; their x tile is WinT16's: 10 floats per column)
+    const size_t lds_g = (size_t)(8 * 3 * (80 + row16(NT)) + 10 * NT), lds_t = best_nb == 25 ? G16<25, 4, 1>::LDS_FLOATS : G16<18, 4, 1>::LDS_FLOATS;
     const size_t lds = (lds_g > lds_t ? lds_g : lds_t) * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)((P + NP - 1) / NP)), dim3(NTHREADS), lds, (hipStream_t)stream, sp);

@@ -103,6 +103,55 @@ struct Win16 {
     }
 };
 
+// Channel-INTERLEAVED staging of 8 channel rows x NSL slots x NP positions for the graph conv's aggregation phase: position
+// `pos` of the tile (slot-major, 0 .. NSL * NP - 1) keeps channels 0-3 in four consecutive floats at xt_off(pos) and channels
+// 4-7 at XT_HALF + xt_off(pos), so a lane fetches the 8 channels of one source joint with two ds_read_b128 instead of eight
+// ds_read_b32 (the aggregation phase is bound by the NUMBER of LDS instructions: 48 gathers per column and chunk before).
+// A position quad is 16 floats + 4 of padding: consecutive positions stay 16 bytes apart inside a quad (the gathers of
+// neighbouring columns fall on neighbouring banks) and the transposing commit -- lanes = (quad, channel), four ds_write_b32
+// each -- spreads 8 quads x 4 channels over all 32 banks.  Unit e = (slot, quad, channel), CHANNEL fastest: a wave's load
+// covers 8 quads = 128 contiguous bytes of each of the 8 channel rows.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int XT_QUAD = 20;
+__host__ __device__ constexpr int xt_off(int pos) { return (pos >> 2) * XT_QUAD + (pos & 3) * 4; }
+template <int NSL, int NP, bool PARTIAL = false>
+struct WinT16 {
+    static constexpr int Q = NP / 4, U = 8 * NSL * Q, NSW = (U + NTHREADS - 1) / NTHREADS, HALF = NSL * Q * XT_QUAD;
+    static_assert(2 * HALF * 4 < 65536 * 4, "LDS offsets");
+    unsigned goff[NSW];
+    unsigned short loff[NSW];      // float offset of (quad, channel) in the interleaved tile
+    unsigned gback[PARTIAL ? NSW : 1];
+    f32x4 v[NSW];
+    __device__ __forceinline__ void setup(int first, int step, int slots, int64_t slot_stride, int64_t chan_stride, int pmax, int tid,
+                                          int nreal = 8) {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            const int e = min(u * NTHREADS + tid, U - 1);
+            const int kk = e & 7, qi = e >> 3, i = qi % Q, w = qi / Q;
+            const int64_t so = (int64_t)((first + w * step) % slots) * slot_stride + (int64_t)kk * chan_stride + min(4 * i, pmax);
+            goff[u] = (unsigned)(so * 4);
+            if (PARTIAL) gback[u] = (unsigned)((int64_t)max(kk - (nreal - 1), 0) * chan_stride * 4);
+            loff[u] = (unsigned short)((kk >> 2) * HALF + qi * XT_QUAD + (kk & 3));
+        }
+    }
+    __device__ __forceinline__ void issue_sel(const float *__restrict__ base, bool partial) {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            unsigned g = goff[u] - (partial ? gback[PARTIAL ? u : 0] : 0u);
+            asm volatile("" : "+v"(g));
+            v[u] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + g);
+        }
+    }
+    __device__ __forceinline__ void commit(float *__restrict__ Xt) const {
+#pragma unroll
+        for (int u = 0; u < NSW; ++u) {
+            float *d = Xt + loff[u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[4 * j] = v[u][j];
+        }
+    }
+};
+
 // weights: NTAPS x KCHX channel rows x 64 output channels of the packed [tap][Cpad][Mpad] layout -> Wl[(r * KCHX + kk)][LDW];
 // ENTRY: rows in the graph conv's k order instead (gcn_entry below)
 __host__ __device__ constexpr int gcn_entry(int kk, int r, int R) { return ((kk >> 1) * R + r) * 2 + (kk & 1); }
@@ -156,25 +205,25 @@ __device__ __forceinline__ void stagger_odd_slot(int units) {
 #ifndef CSK_READ_AHEAD
 #define CSK_READ_AHEAD 2
 #endif
-template <int NM>
+template <int NM, int AH = CSK_READ_AHEAD>
 __device__ __forceinline__ void mfma16_read_ahead() {
-#if CSK_READ_AHEAD > 0
-    __builtin_amdgcn_sched_group_barrier(0x100, 1 + CSK_READ_AHEAD, 0);   // DS reads: the weight fragment + the first activation pairs
+    if (AH > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + AH, 0);           // DS reads: the weight fragment + the first activation pairs
 #pragma unroll
-    for (int i = 0; i < (NM + 1) / 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                // two MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                // one DS read
+        for (int i = 0; i < (NM + 1) / 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);            // two MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // one DS read
+        }
     }
-#endif
 }
 
 // one tap (one k-step of 4 channels): acc[cb] += act[16 cb .. + 15][k] x w[k][16 channels]
-template <int NB>
+template <int NB, int AH = CSK_READ_AHEAD>
 __device__ __forceinline__ void mfma16_tap(const float *__restrict__ wl, const float *__restrict__ bl, f32x4 (&acc)[NB]) {
     const float wf = wl[0];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bl[16 * cb], wf, acc[cb], 0, 0, 0);
-    mfma16_read_ahead<NB>();
+    mfma16_read_ahead<NB, AH>();
 }
 
 // Epilogue shared by the kernels of this file: out = [ReLU](acc + bias + identity residual).  A lane holds positions
