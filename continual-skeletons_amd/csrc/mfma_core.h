@@ -324,7 +324,11 @@ __device__ __forceinline__ void mfma_taps(const float *__restrict__ Wl, const fl
 // the LDS fragment reads of tap r + 1 under the MFMAs of tap r.  The rolled loop above exposes the LDS latency once per
 // tap, which a wave only hides while its SIMD partner (the other workgroup's wave) is issuing MFMAs too -- not while the
 // partner sits in its barrier / commit phase and this wave has the matrix pipe to itself.
-template <int MT, int NTAPS>
+// AH > 0: the operand reads of k-step i + AH are issued under the MFMAs of k-step i (sched_group_barrier; see mfma16_read_ahead
+// in tile16.h).  For launches whose workgroups run ALONE on their CU (the split-K clip latency path: one wave per SIMD, nobody
+// to fill the LDS round trip the default schedule -- read, s_waitcnt lgkmcnt(0), four MFMAs -- exposes per k-step); with two
+// workgroups per CU and many rounds it measured nothing (clip forward, batch 256: 69.7-70.1 ms either way).
+template <int MT, int NTAPS, int AH = 0>
 __device__ __forceinline__ void mfma_taps_ct(const float *__restrict__ Wl, const float *__restrict__ Bl, int r0, int ldb, int tapB,
                                              int offA, int off0, int off1, int kh, f32x16 (&acc)[2][2]) {
     const float *wr = Wl + r0 * (KC * MT) + offA + kh * MT;
@@ -339,6 +343,14 @@ __device__ __forceinline__ void mfma_taps_ct(const float *__restrict__ Wl, const
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    if (AH > 0) {                                                  // per k-step: one ds_read2 (A) + two ds_read (B), four MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * AH, 0);
+#pragma unroll
+        for (int i = 0; i < NTAPS * (KC / 2); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
         }
     }
 }

@@ -420,7 +420,9 @@ int launch16(StepParams p, int n_emit, hipStream_t s) {
     typedef G16<NB, E, HS> G;
     p.gx = (unsigned)((p.P + G::NP - 1) / G::NP); p.gy = (unsigned)(p.Mpad / 64); p.gz = (unsigned)(n_emit / E);
     if ((int64_t)p.gx * p.gy * p.gz >= (1ll << 31)) CSK_FAIL("tcn_step: grid too large");
-    const bool tail = (p.C % G::KCH) != 0 || (p.res_mode == CSK_RES_CONV && (p.Cres % G::KR) != 0);
+    // the fast instantiation walks Cpad (CresPad) channel rows: it is only for operands without padding rows -- a channel count
+    // that is a multiple of the chunk but not of CSK_CPAD (C = 4, 8: test shapes) would read up to 12 rows past the last ring slot
+    const bool tail = p.Cpad != p.C || (p.res_mode == CSK_RES_CONV && p.CresPad != p.Cres);
     p.stagger = stagger_units("CSK_TCN16_STAGGER", TCN16_STAGGER) | (prio_mode("CSK_TCN16_PRIO", TCN16_PRIO) << 16);
     p.stamps = csk_diag_stamps();
     void (*kern)(StepParams) = tail ? tcn_step16_kernel<NB, E, HS, true> : tcn_step16_kernel<NB, E, HS, false>;
@@ -516,7 +518,8 @@ int csk_launch_co_stack16(int n_blocks, const csk_co_block_args *b, int n_skel, 
     sp.nblk = n_blocks;
     for (int i = 0; i < n_blocks; ++i) {
         const csk_co_block_args &a = b[i];
-        if (a.c_out > 64 || (a.c_out & 3) || a.ell_cnt[0] > 1 || a.ell_cnt[1] > 1 || a.ell_cnt[2] > 4) return -2;
+        // (c_out a multiple of CSK_CPAD: the stack's temporal step is the instantiation without padding rows)
+        if (a.c_out > 64 || (a.c_out % CSK_CPAD) || a.ell_cnt[0] > 1 || a.ell_cnt[1] > 1 || a.ell_cnt[2] > 4) return -2;
         // a conv gcn_residual (c_in != c_out: the first block of a network) has a fourth operand subset and with it the register
         // budget of a kernel of its own: such a block runs as its two launches
         if (a.gcn_res_mode != CSK_RES_IDENTITY) return -2;

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                              // staging registers then spill and the stage runs 13-19 % slower
     constexpr int NT = 16384 / MT;
     constexpr int WM = MT / 64;
+    constexpr int LAT_AHEAD = SPLIT ? 2 : 0;   // operand reads two k-steps ahead where a workgroup has its CU to itself (mfma_core.h)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Wl = smem;
     float *Bl = smem + p.K * KC * MT;
@@ -164,21 +165,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
                     // raised priority while in an MFMA segment: this wave then wins issue arbitration against the
                     // SIMD partner's commit / load-issue phase (+2 % measured)
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
-                    if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 0, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    if (CT) mfma_taps_ct<MT, 3, LAT_AHEAD>(Wl, Bl, 0, p.ldb, V, offA, off[0], off[1], kh, acc);
                     else mfma_taps<MT>(Wl, Bl, 0, t1, p.ldb, V, offA, off[0], off[1], kh, acc);
                     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                     for (int j = 3; j < 6; ++j) ws1.issue_slot(j, wnext);
                     bx.template issue_third<1>(seg_base, Cl, cs, cn, wave);
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
-                    if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 3, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    if (CT) mfma_taps_ct<MT, 3, LAT_AHEAD>(Wl, Bl, 3, p.ldb, V, offA, off[0], off[1], kh, acc);
                     else if (t1 < t2) mfma_taps<MT>(Wl, Bl, t1, t2, p.ldb, V, offA, off[0], off[1], kh, acc);
                     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                     for (int j = 6; j < 9; ++j) ws1.issue_slot(j, wnext);
                     bx.template issue_third<2>(seg_base, Cl, cs, cn, wave);
                     if (p.prio) __builtin_amdgcn_s_setprio(1);
-                    if (CT) mfma_taps_ct<MT, 3>(Wl, Bl, 6, p.ldb, V, offA, off[0], off[1], kh, acc);
+                    if (CT) mfma_taps_ct<MT, 3, LAT_AHEAD>(Wl, Bl, 6, p.ldb, V, offA, off[0], off[1], kh, acc);
                     else if (t2 < p.K) mfma_taps<MT>(Wl, Bl, t2, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
                     __builtin_amdgcn_s_setprio(0);
                 }
@@ -205,9 +206,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage_kernel(const TcnParams 
         if (!conv_res && OCC == 2) { load_half(0); load_half(1); }
         if (K9 && NJ < 9 && !p.no_peel_ct) {   // the peeled last chunk in straight-line 3-tap segments too, where the register budget allows
                                                // (+0.1 ... +0.7 %; diagnostic CSK_TCN_NOPEELCT keeps it rolled)
-            mfma_taps_ct<MT, 3>(Wl, Bl, 0, p.ldb, V, offA, off[0], off[1], kh, acc);
-            mfma_taps_ct<MT, 3>(Wl, Bl, 3, p.ldb, V, offA, off[0], off[1], kh, acc);
-            mfma_taps_ct<MT, 3>(Wl, Bl, 6, p.ldb, V, offA, off[0], off[1], kh, acc);
+            mfma_taps_ct<MT, 3, LAT_AHEAD>(Wl, Bl, 0, p.ldb, V, offA, off[0], off[1], kh, acc);
+            mfma_taps_ct<MT, 3, LAT_AHEAD>(Wl, Bl, 3, p.ldb, V, offA, off[0], off[1], kh, acc);
+            mfma_taps_ct<MT, 3, LAT_AHEAD>(Wl, Bl, 6, p.ldb, V, offA, off[0], off[1], kh, acc);
         } else {
             mfma_chunk<MT>(Wl, Bl, p.K, p.ldb, V, offA, off[0], off[1], kh, acc);
         }

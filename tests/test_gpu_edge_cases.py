@@ -220,3 +220,45 @@ def test_nan_propagates_through_relu_epilogues():
             outs.append(o_)
     z = torch.stack(outs, dim=2)                                         # step s emits clip frame s - 4
     assert bool(torch.isnan(z[0, :, 5, 7]).all()) and bool(torch.isfinite(z[0, :, 0, 0]).all())
+
+
+@pytest.mark.parametrize("c,res", [(4, 1), (8, 1), (8, 0), (12, 1), (6, 1), (16, 1)])
+def test_tcn_step_never_reads_behind_the_last_ring_slot(c, res):
+    """Channel counts that are whole 4-channel chunks but not whole CSK_CPAD = 16 blocks: the packed weights have padding rows,
+    the state ring has none.  The ring sits at the END of a buffer whose tail is NaN (then zero): a kernel that walks the padding
+    rows reads them behind the last slot -- NaN x 0 = NaN in the output; on a box where the ring ends at the end of a mapping the
+    same read is a GPU memory fault (seen in round 6: csk_tcn_step_f32's fast instantiation took C = 4 and C = 8)."""
+    from continual_skeletons_amd import native
+    lib = native.lib()
+    P, slots = 176, 12
+    tc = pkg.TemporalConvolution(c, c, kernel_size=9, stride=1, padding=4).eval()
+    import bench
+    bench.randomise_(tc, 3)
+    tc = tc.to(DEV)
+    ops = tc._packed_ops(torch.device(DEV))
+    g = torch.Generator().manual_seed(c)
+    ring_h = torch.rand((slots, c, P), generator=g)
+    xres_h = torch.rand((8, c, P), generator=g)
+    outs = []
+    for fill in (float("nan"), 0.0):
+        buf = torch.full((slots * c * P + 16 * P,), fill, device=DEV)
+        ring = buf[: slots * c * P].view(slots, c, P)
+        ring.copy_(ring_h)
+        xbuf = torch.full((8 * c * P + 16 * P,), fill, device=DEV)
+        xres = xbuf[: 8 * c * P].view(8, c, P)
+        xres.copy_(xres_h)
+        out = torch.zeros((4, c, P), device=DEV)
+        # head = slots - 1: the newest frame is in the LAST physical slot (the window is slots 3 .. 11); xres slot 7 likewise
+        rc = lib.csk_tcn_step_f32(native.ptr(ring), slots, slots - 1, 1, 1, native.ptr(ops["w"]), native.ptr(xres) if res else None, 8, 7, 1,
+                                  None, native.ptr(ops["bias"]), native.ptr(out), 4, 0, c, c, P, 9, res, c if res else 0, 1, 1, None,
+                                  native.stream_of(ring))
+        native.check(rc, "csk_tcn_step_f32")
+        torch.cuda.synchronize()
+        outs.append(out[0].cpu())
+    assert bool(torch.isfinite(outs[0]).all()), "the kernel read rows behind the last ring slot"
+    assert torch.equal(outs[0], outs[1])
+    # and the value: the module's clip forward over the 9 window frames (slots 3 .. 11), centre frame, + identity residual, ReLU
+    x = ring_h[3:12].view(9, c, 8, 22).permute(2, 1, 0, 3).contiguous()          # positions as 8 "samples" x 22 "joints": (N, C, T, V)
+    clip = tc(x.to(DEV))[:, :, 4].permute(1, 0, 2).reshape(c, P).cpu()
+    want = torch.relu(clip + (xres_h[7] if res else 0))
+    check_parity(outs[0], want)
