@@ -262,3 +262,85 @@ def test_tcn_step_never_reads_behind_the_last_ring_slot(c, res):
     clip = tc(x.to(DEV))[:, :, 4].permute(1, 0, 2).reshape(c, P).cpu()
     want = torch.relu(clip + (xres_h[7] if res else 0))
     check_parity(outs[0], want)
+
+
+def _guarded(t, fill, pad=1 << 16):
+    """A copy of `t` inside a larger buffer whose `pad` elements in FRONT of it and behind it hold `fill` (NaN: a kernel that reads
+    outside its operand -- against a zero weight, or for a lane it later masks -- shows up as NaN in the output; on a box where the
+    operand ends a mapping the same read is a memory fault)."""
+    buf = torch.full((t.numel() + 2 * pad,), fill, device=DEV)
+    v = buf[pad: pad + t.numel()].view(t.shape)
+    v.copy_(t)
+    return v
+
+
+@pytest.mark.parametrize("ci,co,frames,skel", [(64, 64, 4, 2048), (3, 64, 4, 2048), (128, 256, 2, 2048), (12, 24, 4, 2048),
+                                               (64, 64, 4, 7), (6, 6, 1, 3), (256, 256, 1, 2047)])
+def test_graph_conv_step_shapes_read_only_their_input(ci, co, frames, skel):
+    """csk_gcn_stage_f32 on channel-major frames (the continual engine's call): at 2048 skeletons the slot-balanced tiles
+    (gcn16_kernel), at small sizes the 32x32x2 kernel; ragged channel counts and a ragged last tile.  The input sits between NaN
+    guards: the output must be finite and the same as with zero guards."""
+    torch.manual_seed(ci + co)
+    g = pkg.GraphConvolution(ci, co, pkg.ntu_graph().A).eval()
+    import bench
+    bench.randomise_(g, 1)
+    g = g.to(DEV)
+    P = (skel * 25 + 3) // 4 * 4
+    x_h = torch.rand((frames, ci, P))
+    outs = []
+    for fill in (float("nan"), 0.0):
+        x = _guarded(x_h.to(DEV), fill)
+        y = torch.zeros((frames, co, P), device=DEV)
+        g.stage(x, y, n_seg=frames, frames=skel, x_strides=(ci * P, P), y_strides=(co * P, P))
+        torch.cuda.synchronize()
+        outs.append(y[:, :, : skel * 25].cpu())
+    assert bool(torch.isfinite(outs[0]).all()), "the kernel read outside x"
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("c,co,t,stride,v", [(64, 64, 20, 1, 25), (64, 128, 21, 2, 25), (64, 64, 16, 1, 25), (128, 128, 37, 1, 18),
+                                             (256, 256, 9, 1, 18), (128, 256, 30, 2, 18), (8, 8, 20, 1, 25), (128, 128, 20, 1, 25)])
+def test_temporal_conv_clip_shapes_read_only_their_input(c, co, t, stride, v):
+    """csk_tcn_stage_f32 (16-wide tile family where the policy takes it, the 32x32x2 kernel elsewhere): frame counts that are
+    not whole tiles, stride 2 with an odd count, the zero padding at both ends.  Input between NaN guards: finite output, equal
+    to the run with zero guards."""
+    torch.manual_seed(c + t)
+    tc = pkg.TemporalConvolution(c, co, kernel_size=9, stride=stride, padding=4).eval()
+    import bench
+    bench.randomise_(tc, 2)
+    tc = tc.to(DEV)
+    x_h = torch.rand((3, c, t, v))
+    outs = []
+    for fill in (float("nan"), 0.0):
+        outs.append(tc(_guarded(x_h.to(DEV), fill)).cpu())
+    assert bool(torch.isfinite(outs[0]).all()), "the kernel read outside its input"
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("ci,co,mode", [(3, 64, "step"), (64, 64, "step"), (128, 256, "step"), (64, 128, "clip"), (3, 64, "clip")])
+def test_adaptive_graph_conv_reads_only_its_input(ci, co, mode):
+    """A-GCN / CoAGCN (Kinetics joints): embedding + attention + dense graph conv launches with the input between NaN guards --
+    step form on channel-major frames (511 skeletons: a ragged last tile), clip form on (N, C, T, V) with T = 23."""
+    torch.manual_seed(ci)
+    A = pkg.kinetics_graph().A
+    g = pkg.AdaptiveGraphConvolution(ci, co, A).eval()
+    import bench
+    bench.randomise_(g, 4, attn_scale=1 / 18)
+    g = g.to(DEV)
+    outs = []
+    if mode == "step":
+        skel, frames = 511, 2
+        P = skel * 18 + 2
+        x_h = torch.rand((frames, ci, P))
+        for fill in (float("nan"), 0.0):
+            x = _guarded(x_h.to(DEV), fill)
+            y = torch.zeros((frames, co, P), device=DEV)
+            g.stage(x, y, n_seg=frames, frames=skel, x_strides=(ci * P, P), y_strides=(co * P, P))
+            torch.cuda.synchronize()
+            outs.append(y[:, :, : skel * 18].cpu())
+    else:
+        x_h = torch.rand((3, ci, 23, 18))
+        for fill in (float("nan"), 0.0):
+            outs.append(g(_guarded(x_h.to(DEV), fill)).cpu())
+    assert bool(torch.isfinite(outs[0]).all()), "a kernel read outside x"
+    assert torch.equal(outs[0], outs[1])
