@@ -344,3 +344,42 @@ def test_adaptive_graph_conv_reads_only_its_input(ci, co, mode):
             outs.append(g(_guarded(x_h.to(DEV), fill)).cpu())
     assert bool(torch.isfinite(outs[0]).all()), "a kernel read outside x"
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("ci,co,res,stride", [(4, 4, True, 1), (8, 8, True, 1), (12, 12, False, 1), (3, 8, False, 1), (6, 6, True, 1),
+                                              (64, 64, True, 1), (8, 16, True, 2), (64, 128, True, 2)])
+def test_block_step_with_the_rings_between_nan_guards(ci, co, res, stride, fuse):
+    """A continual block's cycle (graph conv of the new frames + emitting temporal steps; fused and as two launches) with its
+    three rings re-seated between NaN guards: the rings and the emissions must be the ones of the block whose rings sit between
+    zero guards -- no launch reads a row outside a ring (channel counts with weight padding rows: 4, 8, 12; 7 skeletons in 176
+    positions: a ragged tile; stride 2: emissions every other frame)."""
+    import bench
+    blocks, states = [], []
+    for fill in (float("nan"), 0.0):
+        torch.manual_seed(1)
+        b = pkg.CoSpatioTemporalBlock(ci, co, pkg.ntu_graph().A, stride, residual=res, padding="equal").eval()
+        bench.randomise_(b, 2)
+        b = b.to(DEV)
+        b.fuse_step = fuse
+        st = b.bind_state(176, torch.device(DEV))
+        st.y, st.out, st.xin = _guarded(st.y, fill), _guarded(st.out, fill), _guarded(st.xin, fill)
+        blocks.append(b)
+        states.append(st)
+    g = torch.Generator().manual_seed(4)
+    got = None
+    for cyc in range(9):
+        x = torch.rand((4, ci, 176), generator=g).to(DEV)
+        rets = []
+        for b, st in zip(blocks, states):
+            for f in range(4):
+                st.xin[(st.s + f) % st.xin.shape[0]] = x[f]
+            rets.append(b.engine_advance(4, 7, 25))
+        torch.cuda.synchronize()
+        assert rets[0] == rets[1]
+        for name in ("y", "out"):
+            a_, b_ = getattr(states[0], name), getattr(states[1], name)
+            assert bool(torch.isfinite(a_).all()), (cyc, name, "a launch read outside a ring")
+            assert torch.equal(a_, b_), (cyc, name)
+        got = rets[0]
+    assert got is not None
