@@ -173,18 +173,23 @@ def _scratch_of(module) -> SplitScratch:
     return sc
 
 
-def set_clip_latency_mode(module: nn.Module, split_k: int = 4, gcn_split_k: int = None) -> nn.Module:
+CLIP_SPLIT_MAX_SEQUENCES = 6   # N * M up to which the split forward is the faster one (NTU batch 3); measured: profiles/HISTORY.md r5 #4, r6 #18
+
+
+def set_clip_latency_mode(module: nn.Module, split_k: int = 4, gcn_split_k: int = None, max_sequences: int = CLIP_SPLIT_MAX_SEQUENCES) -> nn.Module:
     """Small-batch clip inference (the reference's own CPU protocol is batch 1, scripts/benchmark_all_ntu60.py:17).
 
     At a few clips a stage launch is a few dozen tiles on 256 CUs, each walking its whole K loop alone (a 256-channel
     temporal conv: 2 x 15 x 2 = 60 workgroups x 288 K-chunks at batch 1).  With ``split_k`` > 1 every 9 x 1 temporal conv
     and every plain graph conv (>= 16 input channels) below ``module`` cuts its K loop into ``split_k`` channel ranges
     computed by separate workgroups (csk_tcn_stage_splitk_f32 / csk_gcn_stage_splitk_f32) and summed in split order by a
-    second launch.  The factor is a function of ``split_k`` and the layer's channel count ONLY -- never of the batch -- so
-    a clip's logits do not depend on how many clips share the forward; against the default mode they differ by the
-    summation order (parity with the oracle within the same 1e-4).  ``split_k`` <= 1 switches it off.  Costs throughput
-    at large batches (partial sums travel through HBM): use it for N * M of up to a few dozen sequences.
-    ``gcn_split_k`` (default: ``split_k``) sets the graph convs' factor separately."""
+    second launch.  The factor is a function of ``split_k`` and the layer's channel count ONLY, and it applies to forwards
+    of at most ``max_sequences`` skeleton sequences (N * M; default 6 = NTU batch 3) -- larger forwards run the default
+    kernels, which are the faster ones from there on (batch 8: 2.9 ms against 3.5 ms split), so the mode is never slower
+    than the default.  A clip's logits are therefore bitwise the same alone and in any batch on the same side of that
+    bound; across it (and against the default mode) they differ by the summation order (parity with the oracle within the
+    same 1e-4).  ``split_k`` <= 1 switches it off.  ``gcn_split_k`` (default: ``split_k``) sets the graph convs' factor
+    separately."""
     gcn_split_k = split_k if gcn_split_k is None else gcn_split_k
     for v in (split_k, gcn_split_k):
         if not isinstance(v, int) or v < 0 or v > 32:
@@ -192,6 +197,8 @@ def set_clip_latency_mode(module: nn.Module, split_k: int = 4, gcn_split_k: int 
     targets = [m for m in module.modules() if isinstance(m, SpatioTemporalBlock) or type(m) is GraphConvolution]
     if not targets:
         raise ValueError("no SpatioTemporalBlock / GraphConvolution below this module: nothing to set")
+    if not isinstance(max_sequences, int) or max_sequences < 1:
+        raise ValueError("max_sequences must be a positive integer")
     # one partial-sum scratch for the whole tree (non-persistent, not part of state_dict); switching the mode off releases it
     old = {id(sc): sc for sc in (m.__dict__.get("_split_scratch") for m in targets) if sc is not None}
     for sc in old.values():
@@ -199,6 +206,7 @@ def set_clip_latency_mode(module: nn.Module, split_k: int = 4, gcn_split_k: int 
     shared = SplitScratch() if max(split_k, gcn_split_k) > 1 else None
     for m in targets:
         m.clip_split_k = split_k if isinstance(m, SpatioTemporalBlock) else gcn_split_k
+        m.clip_split_max_seq = int(max_sequences)
         m.__dict__["_split_scratch"] = shared
     return module
 
@@ -262,7 +270,7 @@ class GraphConvolution(_Folded):
                 self.out_channels, t, v, ops["res_mode"], native.stream_of(x))
             native.check(rc, "csk_gcn_stage_bf16x3")
             return y
-        ks = self._clip_ksplit()
+        ks = self._clip_ksplit() if n <= self.clip_split_max_seq else 1
         if ks > 1:
             self.stage(x, y, n_seg=n, frames=t, x_strides=(c * t * v, t * v), y_strides=(self.out_channels * t * v, t * v),
                        ksplit=ks, partial=_scratch_of(self).get(x.device, ks * n * self.out_channels * t * v))
@@ -271,6 +279,7 @@ class GraphConvolution(_Folded):
         return y
 
     clip_split_k = 0       # set_clip_latency_mode: channel ranges per tile of the clip forward (0 / 1: off)
+    clip_split_max_seq = CLIP_SPLIT_MAX_SEQUENCES   # ... for forwards of at most this many sequences
 
     def _clip_ksplit(self) -> int:
         """Split factor of the clip forward: min(clip_split_k, 8-channel chunks of the K loop) for plain graph convs with
@@ -393,6 +402,7 @@ class SpatioTemporalBlock(_Folded):
 
     precision = "f32"      # or "bf16x3" (opt-in, set_precision): arithmetic of the temporal conv / residual conv kernels
     clip_split_k = 0       # set_clip_latency_mode: channel ranges per tile of the clip forward's temporal conv (0 / 1: off)
+    clip_split_max_seq = CLIP_SPLIT_MAX_SEQUENCES   # ... for forwards of at most this many sequences
 
     def _watched(self):    # the tail's operands are folded from the temporal conv and the residual conv; the graph conv keeps its own cache
         return [m for m in (self.tcn, self.residual) if isinstance(m, nn.Module)]
@@ -423,7 +433,7 @@ class SpatioTemporalBlock(_Folded):
         if self.precision == "bf16x3":
             return tcn_stage(y, ops["w_split"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
                              res_mode=mode, x_res=xr, w_res=ops["w_res_split"], res_off=shrink, out=out, split=True)
-        ks = max(1, min(self.clip_split_k, -(-ops["c"] // 8))) if (self.clip_split_k > 1 and ops["k"] == 9) else 1
+        ks = max(1, min(self.clip_split_k, -(-ops["c"] // 8))) if (self.clip_split_k > 1 and ops["k"] == 9 and y.shape[0] <= self.clip_split_max_seq) else 1
         return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
                          res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out, ksplit=ks,
                          scratch=_scratch_of(self) if ks > 1 else None)

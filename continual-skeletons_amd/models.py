@@ -80,7 +80,8 @@ class StGcn(_Folded):
         n, c, t, v, m = x.shape
         return self.head(self.features(x), n, m)
 
-    def set_latency_mode(self, split_k: int = 4, gcn_split_k: int = None):
-        """Small-batch clip inference: split the K loops of every block over workgroups (blocks.set_clip_latency_mode)."""
-        from .blocks import set_clip_latency_mode
-        return set_clip_latency_mode(self, split_k, gcn_split_k)
+    def set_latency_mode(self, split_k: int = 4, gcn_split_k: int = None, max_sequences: int = None):
+        """Small-batch clip inference: split the K loops of every block over workgroups for forwards of at most
+        ``max_sequences`` sequences (N * M; default 6), the default kernels above that (blocks.set_clip_latency_mode)."""
+        from .blocks import CLIP_SPLIT_MAX_SEQUENCES, set_clip_latency_mode
+        return set_clip_latency_mode(self, split_k, gcn_split_k, CLIP_SPLIT_MAX_SEQUENCES if max_sequences is None else max_sequences)

@@ -314,7 +314,15 @@ def test_clip_latency_mode_full_model_golden_and_batch_invariance():
     check_parity(both, base, note="latency mode vs default (summation order)")
     one = net(x[:1].to(DEV)).cpu()
     assert torch.equal(one, both[:1])                         # batch-invariant for a fixed split_k
+    # above max_sequences (default 6 = batch 3 at M = 2) the mode runs the default kernels: never slower than the default mode,
+    # bitwise the default mode's logits
+    x4 = torch.cat([x, x]).to(DEV)
+    big = net(x4).cpu()
+    net.set_latency_mode(4, max_sequences=8)                  # ... a bound that takes batch 4 in
+    big_split = net(x4).cpu()
+    assert torch.equal(big_split[:2], both) and torch.equal(big_split[2:], both)
     net.set_latency_mode(0)
     assert torch.equal(net(x.to(DEV)).cpu(), base)
+    assert torch.equal(net(x4).cpu(), big) and torch.equal(big[:2], base)
     with pytest.raises(ValueError):
         pkg.set_clip_latency_mode(torch.nn.Linear(2, 2))

@@ -19,6 +19,7 @@ ap.add_argument("--split-k", default="0,2,4,6,8,12,16")
 ap.add_argument("--trace", action="store_true")
 ap.add_argument("--gcn-split-k", type=int, default=-1)
 ap.add_argument("--forwards", type=int, default=200)
+ap.add_argument("--max-seq", type=int, default=None, help="max_sequences of set_latency_mode (default: the library's 6)")
 a = ap.parse_args()
 pkg = _bootstrap.load()
 dev = "cuda:0"
@@ -27,7 +28,7 @@ bench.randomise_(net, 0)
 net = net.to(dev)
 x = torch.rand((a.batch, 3, 300, 25, 2), device=dev, generator=torch.Generator(device=dev).manual_seed(41))
 for sk in [int(v) for v in a.split_k.split(",")]:
-    net.set_latency_mode(sk, None if a.gcn_split_k < 0 else a.gcn_split_k)
+    net.set_latency_mode(sk, None if a.gcn_split_k < 0 else a.gcn_split_k, a.max_seq)
     for _ in range(3):
         out = net(x)
     torch.cuda.synchronize()
@@ -49,5 +50,5 @@ for sk in [int(v) for v in a.split_k.split(",")]:
         g.replay()
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    print(f"CLIP_LATENCY_PASS batch={a.batch} split_k={sk} gcn_split_k={a.gcn_split_k} graph_ms_p50={statistics.median(ts) * 1e3:.4f} "
+    print(f"CLIP_LATENCY_PASS batch={a.batch} split_k={sk} gcn_split_k={a.gcn_split_k} max_seq={a.max_seq} graph_ms_p50={statistics.median(ts) * 1e3:.4f} "
           f"p99={sorted(ts)[int(0.99 * (len(ts) - 1))] * 1e3:.4f}")
