@@ -194,31 +194,42 @@ __global__ __launch_bounds__(NTHREADS, TAIL ? 1 : 2) void tcn_step16_kernel(cons
 // count that is not a multiple of 8: the chunk holding the last real channels re-reads the last real row for the rows past it,
 // chunks of padding only re-read that chunk (their packed weights are zero; the value only has to be finite -- the clamp of
 // gcn_stage_sparse2_kernel).
+#ifndef CSK_GCN16_WAVES
+#define CSK_GCN16_WAVES 8      // waves per workgroup of the stand-alone graph-conv launches (4: the round's first form, A/B builds)
+#endif
 #ifndef CSK_GCN_AHEAD
 #define CSK_GCN_AHEAD CSK_READ_AHEAD
 #endif
 constexpr int GCN_AHEAD = CSK_GCN_AHEAD;
-template <int NB, int F, bool CONVRES>
+// NW = 4: a wave owns 16 output channels x all NB column blocks (the form the fused stack runs: 256 threads, shared with the
+// temporal step).  NW = 8 (the stand-alone launches): 512 threads, a wave owns 16 channels x HALF the column blocks -- 52
+// accumulator registers, <= 128 VGPRs, FOUR waves per SIMD at two workgroups per CU: both phases of this kernel are latency chains
+// (LDS gathers -> arithmetic -> LDS writes; operand read -> MFMA), and twice the waves hide twice the latency.
+template <int NB, int F, bool CONVRES, int NW = 4>
 __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, const int qt, const int sg, float *smem) {
     constexpr int R = CONVRES ? 4 : 3, KCG = 8, NE = KCG * R;
     constexpr int NT = 16 * NB, NPG = NT / F, AROW = row16(NT), LDW = 80;
-    typedef WinT16<F, NPG, true> XS;                                   // x rows staged channel-interleaved (tile16.h)
+    constexpr int NTH = 64 * NW, NBW = NW == 8 ? (NB + 1) / 2 : NB;    // threads; column blocks of a wave
+    constexpr int NC = NW == 8 ? 1 : 2;                                // columns a thread aggregates (adjacent ones)
+    typedef WinT16<F, NPG, true, NTH> XS;                              // x rows staged channel-interleaved (tile16.h)
     constexpr int XH = XS::HALF;
-    static_assert(NT % 2 == 0 && NT <= 2 * NTHREADS, "a thread aggregates two adjacent columns");
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    static_assert(NT % NC == 0 && NT <= NC * NTH, "every column has a thread");
     static_assert(NT % F == 0 && NPG % 4 == 0, "a segment's positions are whole 16-byte quads");
     float *Wl = smem, *Ba = smem + NE * LDW, *Xs = Ba + NE * AROW;
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));      // opaque: inside a fused stack the per-thread setup must not be hoisted out of the block loop (and spilled)
     const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
+    const int wm = wave & 3, wh = wave >> 2;                           // 16-channel block; half of the column blocks (NW = 8)
     const int m0 = mt * 64, q0 = qt * NPG, seg0 = sg * F;
     const int V = p.V, Q = p.frames * V;
     const int nval = min(NPG, Q - q0);                                 // valid positions of the tile: whole skeletons
-    f32x4 acc[NB];
+    f32x4 acc[NBW];
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < NBW; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    W16<R, KCG, LDW, true> ws;
+    W16<R, KCG, LDW, true, NTH> ws;
     XS xs;
     const int nfull = p.Cin / KCG, rem = p.Cin % KCG;                  // whole chunks, real channels of the partial one
     const int clast = rem ? nfull : nfull - 1;                         // last chunk with a real channel
@@ -226,8 +237,9 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     xs.setup(p.x_ring_slot0 + seg0, 1, p.x_ring_slots, p.x_seg_stride, p.x_chan_stride, (int)(p.x_chan_stride - 4 - q0), tid, rem ? rem : KCG);
     const float *wbase = p.w + m0;
     const float *xbase = p.x + q0;
-    const float *wl_lane = Wl + kq * LDW + wave * 16 + l15;
-    const float *ba_lane = Ba + kq * AROW + l15;
+    const float *wl_lane = Wl + kq * LDW + wm * 16 + l15;
+    // (NW = 8, NB odd: the second half's last block lies past the tile: not computed, masked by the epilogue)
+    const float *ba_lane = Ba + kq * AROW + l15 + 16 * NBW * wh;
     const int nchunks = p.CinPad / KCG;
     auto issue_x = [&](int c) {                                        // chunk c of the K loop
         const int cc = min(c, clast);
@@ -238,12 +250,12 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     // (behind the first chunk's loads, whose latency covers the table reads)
     // adjacency entries of this thread's two columns c0, c0 + 1 (offsets inside the interleaved x tile); threads past the tile
     // redo its last pair (the same values to the same addresses), a wave with no column of its own skips the phase
-    int eoff[2][6], ioff[2];
-    float eval[2][6];
-    const int c0 = min(2 * tid, NT - 2);
-    const bool p1_wave = wave * 128 < NT;                              // (wave-uniform)
+    int eoff[NC][6], ioff[NC];
+    float eval[NC][6];
+    const int c0 = min(NC * tid, NT - NC);
+    const bool p1_wave = wave * 64 * NC < NT;                          // (wave-uniform)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NC; ++n) {
         const int col = c0 + n;
         const int f = col / NPG, pos = min(col - f * NPG, nval - 1);
         const int t = div_magic(pos, p.vmagic), w = pos - t * V, sb = f * NPG + t * V;
@@ -271,9 +283,9 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
         if (!(p.stagger & 0x10000) && p1_wave) {               // (diagnostic: CSK_GCN16_SKIP=1 times the kernel without its aggregation phase)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                          // channels 4 h .. 4 h + 3 of the chunk
-            f32x2 res[4][3];
+            float res[4][3][NC];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NC; ++n) {
                 // (the six 16-byte gathers of the NEXT round in flight under this round's arithmetic: 4.75 k -> 4.45 k cycles for
                 // the phase, which the partner's MFMA phase lost again -- 6.7 k -> 7.3 k: not kept)
                 f32x4 x[6];
@@ -295,12 +307,20 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) *reinterpret_cast<f32x2 *>(Ba + gcn_entry(4 * h + kk, r, R) * AROW + c0) = res[kk][r];
+                for (int r = 0; r < 3; ++r) {
+                    float *d = Ba + gcn_entry(4 * h + kk, r, R) * AROW + c0;
+                    if constexpr (NC == 2) *reinterpret_cast<f32x2 *>(d) = f32x2{res[kk][r][0], res[kk][r][NC - 1]};
+                    else *d = res[kk][r][0];
+                }
             if (CONVRES) {                                    // fourth "subset": the input itself (the conv gcn_residual's operand)
                 const f32x4 x0 = *reinterpret_cast<const f32x4 *>(Xs + h * XH + ioff[0]);
-                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(Xs + h * XH + ioff[1]);
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(Xs + h * XH + ioff[NC - 1]);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<f32x2 *>(Ba + gcn_entry(4 * h + kk, 3, R) * AROW + c0) = f32x2{x0[kk], x1[kk]};
+                for (int kk = 0; kk < 4; ++kk) {
+                    float *d = Ba + gcn_entry(4 * h + kk, 3, R) * AROW + c0;
+                    if constexpr (NC == 2) *reinterpret_cast<f32x2 *>(d) = f32x2{x0[kk], x1[kk]};
+                    else *d = x0[kk];
+                }
             }
         }
         }
@@ -318,14 +338,17 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
         else if (gmode != 4) { if (((gmode == 3 ? 0 : c) + godd) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
         if (!(p.stagger & 0x20000)) {                          // (diagnostic: CSK_GCN16_SKIP=2: without its MFMA phase)
 #pragma unroll
-        for (int m = 0; m < NE / 4; ++m) mfma16_tap<NB, GCN_AHEAD>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
+        for (int m = 0; m < NE / 4; ++m) {
+            if constexpr (NW == 8 && (NB & 1)) mfma16_tap_opt_last<NBW, GCN_AHEAD>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc, wh == 0);
+            else mfma16_tap<NBW, GCN_AHEAD>(wl_lane + 4 * m * LDW, ba_lane + 4 * m * AROW, acc);
+        }
         }
         __builtin_amdgcn_s_setprio(0);
         if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp3 += t - gq; gq = t; }
         __syncthreads();
         if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); gp4 += t - gq; gq = t; }
     }
-    if (p.stamps && lane == 0) {
+    if (p.stamps && lane == 0 && wave < 4) {
         unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
         o[0] = gst0; o[1] = gq; o[2] = gp0; o[3] = gp1; o[4] = gp2; o[5] = gp3; o[6] = gp4;
         o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
@@ -341,22 +364,23 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
     // in the 256-register conv-residual instantiation)
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
-    epilogue16<NB, F, NPG>(acc, p.bias, p.Cout, m0 + __builtin_amdgcn_readfirstlane(tid2 >> 6) * 16 + (tid2 & 15), (tid2 & 63) >> 4, !CONVRES, true,
-                           p.x, p.y, xslot, oslot, p.x_chan_stride, p.y_chan_stride, q0, nrow, nval);
+    const int wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
+    epilogue16<NBW, F, NPG, false, NW == 8 ? 4 : 5>(acc, p.bias, p.Cout, m0 + (wave2 & 3) * 16 + (tid2 & 15), (tid2 & 63) >> 4, !CONVRES, true,
+                                                     p.x, p.y, xslot, oslot, p.x_chan_stride, p.y_chan_stride, q0, nrow, nval, 16 * NBW * (wave2 >> 2));
 }
 
-template <int NB, int F, bool CONVRES>
-__global__ __launch_bounds__(NTHREADS, 2) void gcn16_kernel(const GcnParams p) {
+template <int NB, int F, bool CONVRES, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gcn16_kernel(const GcnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     stagger_odd_slot(p.stagger & 0xffff);
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
     unsigned long long k0 = 0;
     if (p.stamps) k0 = __builtin_amdgcn_s_memtime();
-    gcn16_tile<NB, F, CONVRES>(p, (int)(wid % p.mtiles), (int)((wid / p.mtiles) % p.qtiles), (int)(wid / (p.mtiles * p.qtiles)), smem);
+    gcn16_tile<NB, F, CONVRES, NW>(p, (int)(wid % p.mtiles), (int)((wid / p.mtiles) % p.qtiles), (int)(wid / (p.mtiles * p.qtiles)), smem);
     if (p.stamps && (threadIdx.x & 63) == 0) {                 // diagnostic: workgroup start / end (stores retired), behind the per-wave records
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long *o = p.stamps + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
-        o[0] = k0; o[1] = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = p.stamps + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 2;
+        if ((threadIdx.x >> 6) < 4) { o[0] = k0; o[1] = __builtin_amdgcn_s_memtime(); }
     }
 }
 
@@ -406,12 +430,13 @@ int launch_gcn16(GcnParams p, int n_seg, hipStream_t s) {
     p.qtiles = (unsigned)((Q + NPG - 1) / NPG); p.mtiles = (unsigned)(p.Mpad / 64);
     const int64_t grid = (int64_t)p.qtiles * p.mtiles * (n_seg / F);
     if (grid >= (1ll << 31)) CSK_FAIL("gcn_stage: grid too large");
-    void (*kern)(GcnParams) = p.R == 4 ? gcn16_kernel<NB, F, true> : gcn16_kernel<NB, F, false>;
+    constexpr int NW = CSK_GCN16_WAVES;
+    void (*kern)(GcnParams) = p.R == 4 ? gcn16_kernel<NB, F, true, NW> : gcn16_kernel<NB, F, false, NW>;
     p.stagger = stagger_units("CSK_GCN16_STAGGER", GCN16_STAGGER) | ((csk_diag_int("CSK_GCN16_SKIP") & 15) << 16) | (prio_mode("CSK_GCN16_PRIO", GCN16_PRIO) << 20);
     p.stamps = csk_diag_stamps();
     const size_t lds = (size_t)(8 * p.R * (80 + row16(NT)) + 2 * WinT16<F, NPG>::HALF) * sizeof(float);
     if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, s, p);
     return (int)hipGetLastError();
 }
 

@@ -114,9 +114,9 @@ struct Win16 {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int XT_QUAD = 20;
 __host__ __device__ constexpr int xt_off(int pos) { return (pos >> 2) * XT_QUAD + (pos & 3) * 4; }
-template <int NSL, int NP, bool PARTIAL = false>
+template <int NSL, int NP, bool PARTIAL = false, int NTH = NTHREADS>
 struct WinT16 {
-    static constexpr int Q = NP / 4, U = 8 * NSL * Q, NSW = (U + NTHREADS - 1) / NTHREADS, HALF = NSL * Q * XT_QUAD;
+    static constexpr int Q = NP / 4, U = 8 * NSL * Q, NSW = (U + NTH - 1) / NTH, HALF = NSL * Q * XT_QUAD;
     static_assert(2 * HALF * 4 < 65536 * 4, "LDS offsets");
     unsigned goff[NSW];
     unsigned short loff[NSW];      // float offset of (quad, channel) in the interleaved tile
@@ -126,7 +126,7 @@ struct WinT16 {
                                           int nreal = 8) {
 #pragma unroll
         for (int u = 0; u < NSW; ++u) {
-            const int e = min(u * NTHREADS + tid, U - 1);
+            const int e = min(u * NTH + tid, U - 1);
             const int kk = e & 7, qi = e >> 3, i = qi % Q, w = qi / Q;
             const int64_t so = (int64_t)((first + w * step) % slots) * slot_stride + (int64_t)kk * chan_stride + min(4 * i, pmax);
             goff[u] = (unsigned)(so * 4);
@@ -155,15 +155,15 @@ struct WinT16 {
 // weights: NTAPS x KCHX channel rows x 64 output channels of the packed [tap][Cpad][Mpad] layout -> Wl[(r * KCHX + kk)][LDW];
 // ENTRY: rows in the graph conv's k order instead (gcn_entry below)
 __host__ __device__ constexpr int gcn_entry(int kk, int r, int R) { return ((kk >> 1) * R + r) * 2 + (kk & 1); }
-template <int NTAPS, int KCHX, int LDW, bool ENTRY = false>
+template <int NTAPS, int KCHX, int LDW, bool ENTRY = false, int NTH = NTHREADS>
 struct W16 {
-    static constexpr int U = NTAPS * KCHX * 16, NSW = (U + NTHREADS - 1) / NTHREADS;
+    static constexpr int U = NTAPS * KCHX * 16, NSW = (U + NTH - 1) / NTH;
     unsigned goff[NSW], loff[NSW];
     f32x4 v[NSW];
     __device__ __forceinline__ void setup(int Cpad, int Mpad, int tid) {
 #pragma unroll
         for (int u = 0; u < NSW; ++u) {
-            const int e = min(u * NTHREADS + tid, U - 1);
+            const int e = min(u * NTH + tid, U - 1);
             const int row = e / 16, m4 = e % 16, r = row / KCHX, kk = row % KCHX;
             goff[u] = (unsigned)(((r * Cpad + kk) * Mpad + m4 * 4) * 4);
             loff[u] = (unsigned)((ENTRY ? gcn_entry(kk, r, NTAPS) : row) * LDW + m4 * 4);
@@ -225,6 +225,15 @@ __device__ __forceinline__ void mfma16_tap(const float *__restrict__ wl, const f
     for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bl[16 * cb], wf, acc[cb], 0, 0, 0);
     mfma16_read_ahead<NB, AH>();
 }
+// ... for a wave whose LAST column block may lie past the tile (`last` wave-uniform: the half-tile waves of an odd block count)
+template <int NB, int AH = CSK_READ_AHEAD>
+__device__ __forceinline__ void mfma16_tap_opt_last(const float *__restrict__ wl, const float *__restrict__ bl, f32x4 (&acc)[NB], bool last) {
+    const float wf = wl[0];
+#pragma unroll
+    for (int cb = 0; cb < NB - 1; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bl[16 * cb], wf, acc[cb], 0, 0, 0);
+    mfma16_read_ahead<NB - 1, AH>();
+    if (last) acc[NB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bl[16 * (NB - 1)], wf, acc[NB - 1], 0, 0, 0);
+}
 
 // Epilogue shared by the kernels of this file: out = [ReLU](acc + bias + identity residual).  A lane holds positions
 // 16 cb + 4 kq .. + 3 (columns = NSLOT slots x NP positions, slot-major) of output channel `ch` for every column block: 16-byte
@@ -235,17 +244,19 @@ __device__ __forceinline__ void mfma16_tap(const float *__restrict__ wl, const f
 // UNAL: channel rows that are not whole 16-byte quads (clip tensors with T * V not a multiple of 4): 4-byte-aligned vector
 // accesses, and the quad that straddles the end of a row is loaded element by element (never clamped: its values would shift).
 typedef float f32x4u16 __attribute__((ext_vector_type(4), aligned(4)));
-template <int NB, int NSLOT, int NP, bool UNAL = false>
+// c_off: first column of the wave's column blocks (a wave that owns only part of the tile's blocks; columns past the tile are
+// masked like the ragged end of a tile).
+template <int NB, int NSLOT, int NP, bool UNAL = false, int EG = 5>
 __device__ __forceinline__ void epilogue16(f32x4 (&acc)[NB], const float *__restrict__ bias_p, int Cout, int ch, int kq, bool ident, bool relu,
                                            const float *__restrict__ xres, float *__restrict__ out, const unsigned (&xslot)[NSLOT],
                                            const unsigned (&oslot)[NSLOT], int64_t x_chan_stride, int64_t o_chan_stride, int p0, int nrow,
-                                           int nval) {
+                                           int nval, int c_off = 0) {
     const bool chv = ch < Cout;
     const int chc = min(ch, Cout - 1);
     const float bias = bias_p[chc];
     const unsigned xrow = (unsigned)(((int64_t)chc * x_chan_stride + p0) * 4), orow = (unsigned)(((int64_t)chc * o_chan_stride + p0) * 4);
     const int pmax = nrow - 4;
-    constexpr int EG = 5, NG = (NB + EG - 1) / EG;
+    constexpr int NG = (NB + EG - 1) / EG;
     // group g + 1's residual loads are issued in front of group g's arithmetic and stores (two groups of registers)
     f32x4 rv[2][EG];
     unsigned oo[2][EG];
@@ -255,7 +266,7 @@ __device__ __forceinline__ void epilogue16(f32x4 (&acc)[NB], const float *__rest
         for (int u = 0; u < EG; ++u) {
             const int cb = g * EG + u;
             if (cb >= NB) continue;
-            const int c = 16 * cb + 4 * kq;                  // first column of this lane's quad: slot j, position pp
+            const int c = 16 * cb + 4 * kq + c_off;          // first column of this lane's quad: slot j, position pp
             int j = 0;
 #pragma unroll
             for (int jj = 1; jj < NSLOT; ++jj) j += (c >= jj * NP) ? 1 : 0;
