@@ -370,7 +370,7 @@ __device__ __forceinline__ void gcn16_tile(const GcnParams &p, const int mt, con
 }
 
 template <int NB, int F, bool CONVRES, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void gcn16_kernel(const GcnParams p) {
+__global__ __launch_bounds__(64 * NW, NW / 2) void gcn16_kernel(const GcnParams p) {   // (second figure: waves per SIMD = two workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     stagger_odd_slot(p.stagger & 0xffff);
     const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
