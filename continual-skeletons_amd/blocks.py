@@ -416,6 +416,8 @@ class SpatioTemporalBlock(_Folded):
         """``out`` (optional, native tail only): preallocated (N, C_out, T_out, V) tensor to write into."""
         self._require_eval()
         native.require_device_f32(x, "SpatioTemporalBlock input")
+        if self._few_channels_fusable(x):
+            return self._forward_few_channels(x, out)
         y = self.gcn(x)                                   # GCN stage kernel (or any user GraphConv module)
         if not self._native_tail:
             # foreign TempConv / residual modules: compose exactly as models/base.py:376-387
@@ -437,6 +439,44 @@ class SpatioTemporalBlock(_Folded):
         return tcn_stage(y, ops["w"], ops["bias"], ops["c_out"], ops["k"], self.stride, self.tcn.padding, relu=True,
                          res_mode=mode, x_res=xr, w_res=ops["w_res"], res_off=shrink, out=out, ksplit=ks,
                          scratch=_scratch_of(self) if ks > 1 else None)
+
+
+def _few_channels_fusable(self, x) -> bool:
+    """Layer 1 of the stacks (st_gcn.py:30): a plain GraphConvolution with <= 4 input channels and a conv gcn_residual, the native
+    9-tap / stride-1 / pad-4 temporal tail, no block residual, exact fp32, no split-K request -> csk_block_few_channels_f32."""
+    if not self.fuse_few_channels or type(self.gcn) is not GraphConvolution or not self._native_tail:
+        return False
+    if self.gcn.in_channels > 4 or self.residual is not zero or self.stride != 1 or self.precision != "f32" or self.residual_shrink:
+        return False
+    if x.dim() != 4 or x.shape[3] not in (18, 25) or self.gcn.precision != "f32":
+        return False
+    if self.clip_split_k > 1 and x.shape[0] <= self.clip_split_max_seq:
+        return False
+    g, t = self.gcn._packed_ops(x.device), self._packed_ops(x.device)
+    return (t["k"] == 9 and self.tcn.padding == 4 and g["res_mode"] == 2 and g["c_out"] % 8 == 0 and g["V"] == x.shape[3]
+            and max(int(v) for v in g["ell_cnt_host"][:2]) <= 1 and int(g["ell_cnt_host"][2]) <= 4)
+
+
+def _forward_few_channels(self, x, out=None):
+    _check_input(x, self.gcn.in_channels, "SpatioTemporalBlock input")
+    g, t = self.gcn._packed_ops(x.device), self._packed_ops(x.device)
+    n, c, tt, v = x.shape
+    if out is None:
+        out = torch.empty((n, t["c_out"], tt, v), device=x.device, dtype=torch.float32)
+    rc = native.lib().csk_block_few_channels_f32(
+        native.ptr(x.contiguous()), native.ptr(g["w"]), native.ptr(g["bias"]), native.ptr(g["ell_src"]), native.ptr(g["ell_val"]),
+        native.ptr(g["ell_cnt_host"]), g["ell_w"], native.ptr(t["w"]), native.ptr(t["bias"]), native.ptr(out), n, c, g["c_out"],
+        t["c_out"], tt, v, self.tcn.padding, native.stream_of(x))
+    native.check(rc, "csk_block_few_channels_f32")
+    return out
+
+
+# Opt-in (default: the two launches).  Measured at batch 256 (tools/ab_first_block.py): block 1 fused 2.61-2.63 ms against 2.58-2.59 ms
+# for its two launches, the forward 69.45 against 69.36 ms -- the graph-conv launch it saves (0.36 ms, 2 GB of HBM traffic) comes
+# back as the serial y phase of every chunk and the recomputed halo; bit for bit the same output either way.
+SpatioTemporalBlock.fuse_few_channels = False
+SpatioTemporalBlock._few_channels_fusable = _few_channels_fusable
+SpatioTemporalBlock._forward_few_channels = _forward_few_channels
 
 
 def tcn_step_launch(*args):

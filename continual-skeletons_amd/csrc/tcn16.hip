@@ -264,6 +264,235 @@ __global__ __launch_bounds__(NTHREADS, 2) void tcn_stage16_kernel(const TcnParam
                                 (int64_t)p.Tres * V, Qout, q0, nval, nval);
 }
 
+// K order of the graph conv for CIN real input channels (csrc/gcn.hip, gcn_entry in tile16.h): entry (channel pair s, subset r,
+// channel 2 s + h) ascending, padding channels left out.  agg_row: (channel, subset) -> position in that order; agg_sub /
+// agg_chan: position -> subset / channel.
+template <int CIN>
+__host__ __device__ constexpr int agg_row(int ci, int r) {
+    int n = 0;
+    for (int e = 0; e < gcn_entry(ci, r, 4); ++e) {              // entries in front of it whose channel is real
+        const int h = e & 1, sr = e >> 1, s = sr / 4;
+        n += (2 * s + h) < CIN ? 1 : 0;
+    }
+    return n;
+}
+template <int CIN>
+__host__ __device__ constexpr int agg_entry(int j) {            // j-th real entry
+    int n = 0;
+    for (int e = 0; e < 64; ++e) {
+        const int h = e & 1, s = (e >> 1) / 4;
+        if ((2 * s + h) < CIN) {
+            if (n == j) return e;
+            ++n;
+        }
+    }
+    return 0;
+}
+// ... as tables of a constexpr object (evaluated by the compiler, whatever the optimiser makes of the loops around their use)
+template <int CIN>
+struct AggTab {
+    int sub[4 * CIN], chan[4 * CIN], row[CIN][4];
+    constexpr AggTab() : sub{}, chan{}, row{} {
+        for (int j = 0; j < 4 * CIN; ++j) {
+            const int e = agg_entry<CIN>(j);
+            sub[j] = (e >> 1) % 4;
+            chan[j] = 2 * ((e >> 1) / 4) + (e & 1);
+        }
+        for (int ci = 0; ci < CIN; ++ci)
+            for (int r = 0; r < 4; ++r) row[ci][r] = agg_row<CIN>(ci, r);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Block with a FEW input channels (layer 1 of the stacks: C_in = 3) as ONE launch: graph conv (3 adjacency subsets + 1x1 conv
+// gcn_residual, BN, ReLU: models/base.py:230-270) formed on the fly inside the temporal conv's tile (models/base.py:376-387,
+// no block residual: st_gcn.py:30).  The two-launch form writes and re-reads y = 64 channels (2 GB at batch 256) for a graph
+// conv of 12 multiply-adds per output; here the tile's input window (C_in x 24 frames) is staged once, its 4 C_in aggregated
+// rows (3 subsets + the input itself) are kept in LDS, and every 8-channel chunk of y is a small MFMA product of them (K = 4 C_in)
+// written right into the operand rows the temporal conv's MFMAs read -- the temporal halo is recomputed (24 of 16 frames): 3 MFMAs
+// per 16 positions and chunk beside the 450 of the temporal conv.  y is BIT FOR BIT the graph-conv kernel's: the same fmaf chain in its K order ((channel pair, subset, channel),
+// csrc/gcn.hip), bias added last, ReLU, and ZERO in the frames of the temporal padding; the temporal conv is tcn_stage16_kernel's.
+struct Fused1Params {
+    TcnParams t;                   // the temporal conv (y unused); C = C_out of the graph conv
+    const float *x, *gw, *gbias;   // block input (n_seg, Cin, Tin, V); packed graph-conv weights [4][CinPad][GMpad], bias
+    const int *ell_src;
+    const float *ell_val;
+    int ell_cnt[3], ell_w, Cin, CinPad, GMpad;
+};
+
+template <int V, int CIN>
+__global__ __launch_bounds__(NTHREADS, 2) void block1_fused16_kernel(const Fused1Params f) {
+    typedef C16<V, 1, 8> G;
+    constexpr int NB = G::NB, NT = G::NT, KCH = 8, LDW = G::LDW, ROW = G::ROW, SPAN = G::SPAN, NCOL = (SPAN + NTHREADS - 1) / NTHREADS;
+    constexpr int NA = 4 * CIN;                                  // aggregated rows, in the graph conv's K order
+    constexpr AggTab<CIN> TAB{};
+    const TcnParams &p = f.t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem, *Bl = smem + G::WSZ, *Ag = Bl + KCH * ROW, *Xw = Bl;   // Xw [CIN][SPAN]: prologue only, in the operand rows' place
+    static_assert(CIN * SPAN <= KCH * ROW, "the input window fits the operand rows");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const unsigned wid = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int m0 = (int)(wid % p.mtiles) * 64, qt = (int)((wid / p.mtiles) % p.qtiles), seg = (int)(wid / (p.mtiles * p.qtiles));
+    const int q0 = qt * NT, t0 = qt * 16;
+    const int Lin = p.Tin * V, Qout = p.Tout * V;
+    const int wstart = (t0 - p.pad) * V;                         // first staged position (a frame boundary; negative in the first tile)
+    const float *xseg = f.x + (int64_t)seg * f.Cin * Lin;
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    W16x9x8<LDW> ws;
+    ws.setup(p.Cpad, p.Mpad, tid);
+    const float *wbase = p.w + m0;
+    ws.issue(wbase);
+    // ---- prologue: the input window, zero outside the sequence; then the aggregated rows of this thread's columns
+    for (int e = tid; e < CIN * SPAN; e += NTHREADS) {
+        const int ci = e / SPAN, i = e - ci * SPAN, pos = wstart + i;
+        Xw[e] = (pos >= 0 && pos < Lin) ? xseg[(int64_t)ci * Lin + pos] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NCOL; ++n) {
+        const int i = min(n * NTHREADS + tid, SPAN - 1);         // (threads past the window redo its last column: the same values)
+        const int lf = i / V, w = i - lf * V;
+        float ev[6];
+        int es[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int r = e < 2 ? e : 2, k = e < 2 ? 0 : e - 2;
+            const bool have = k < f.ell_cnt[r];
+            const int idx = (r * V + w) * f.ell_w + min(k, f.ell_w - 1);
+            es[e] = lf * V + (have ? f.ell_src[idx] : 0);
+            ev[e] = have ? f.ell_val[idx] : 0.f;
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float *xr = Xw + ci * SPAN;
+            const float b0 = ev[0] * xr[es[0]];
+            const float b1 = ev[1] * xr[es[1]];
+            float s2 = ev[2] * xr[es[2]];
+            s2 = fmaf(ev[3], xr[es[3]], s2);
+            s2 = fmaf(ev[4], xr[es[4]], s2);
+            s2 = fmaf(ev[5], xr[es[5]], s2);
+            // (row = position of (channel, subset) in the graph conv's K order)
+            Ag[TAB.row[ci][0] * SPAN + i] = b0;
+            Ag[TAB.row[ci][1] * SPAN + i] = b1;
+            Ag[TAB.row[ci][2] * SPAN + i] = s2;
+            Ag[TAB.row[ci][3] * SPAN + i] = xr[i];
+        }
+    }
+    // graph-conv weight of aggregated row 4 s + kq (the lane's k index), as an offset into the packed [4][CinPad][GMpad] operand
+    constexpr int NCB = (SPAN + 15) / 16;
+    static_assert(16 * NCB <= ROW, "the last column block stays inside an operand row");
+    int woff[NA / 4];
+#pragma unroll
+    for (int s = 0; s < NA / 4; ++s) {
+        int sub = 0, chan = 0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            sub = (j == 4 * s + kq) ? TAB.sub[j] : sub;
+            chan = (j == 4 * s + kq) ? TAB.chan[j] : chan;
+        }
+        woff[s] = (sub * f.CinPad + chan) * f.GMpad;
+    }
+    const float *wl_lane = Wl + kq * LDW + wave * 16 + l15;
+    const int abase = kq * ROW + l15;
+    auto taps = [&](int r0, int r1) {
+#pragma unroll
+        for (int r = r0; r < r1; ++r) {
+            if (r > r0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KCH / 4; ++s) {
+                const float wf = wl_lane[(r * KCH + 4 * s) * LDW];
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bl[abase + 4 * s * ROW + r * V + 16 * cb], wf, acc[cb], 0, 0, 0);
+            }
+        }
+    };
+    // graph-conv weights / bias of the lane's channel c0 + (l15 & 7), loaded one chunk ahead
+    float wg[NA / 4], bv;
+    auto load_wg = [&](int c0) {
+        const int cw = min(c0 + (l15 & 7), p.C - 1);             // (channels past C: zero temporal weights)
+#pragma unroll
+        for (int s = 0; s < NA / 4; ++s) wg[s] = f.gw[woff[s] + cw];
+        bv = f.gbias[cw];
+    };
+    float wgn[NA / 4], bvn;
+    load_wg(0);
+    // ---- K loop over 8-channel chunks of y
+    for (int c0 = 0; c0 < p.Cpad; c0 += KCH) {
+        __syncthreads();                                         // the previous chunk's operand reads are done (first: Ag is complete)
+        ws.commit(Wl);
+        {   // y rows of the chunk: D[16 positions][16 channels] = agg[16 pos][NA] x Wg[NA][channels] by 16x16x4 MFMAs -- the fmaf
+            // chain of the graph-conv kernel in its K order (an MFMA sums its k values in ascending order); the lanes of channels
+            // 8-15 repeat 0-7 and are not stored.  A lane holds 4 consecutive positions of channel c0 + (l15 & 7).
+            // (the chunk's graph-conv weights and bias were loaded under the previous chunk's MFMAs; three column blocks at a time:
+            // three independent accumulation chains)
+            constexpr int CBU = 3, WV = NTHREADS / 64;
+            for (int cb0 = wave; cb0 < NCB; cb0 += CBU * WV) {
+                f32x4 d[CBU];
+                float av[CBU][NA / 4];
+#pragma unroll
+                for (int u = 0; u < CBU; ++u) {
+                    d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int ci = min(16 * (cb0 + u * WV) + l15, SPAN - 1);
+#pragma unroll
+                    for (int s = 0; s < NA / 4; ++s) av[u][s] = Ag[(4 * s + kq) * SPAN + ci];
+                }
+#pragma unroll
+                for (int s = 0; s < NA / 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < CBU; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], wg[s], d[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < CBU; ++u) {
+                    const int cb = cb0 + u * WV;
+                    if (l15 < 8 && cb < NCB) {
+                        const int i0 = 16 * cb + 4 * kq;
+                        f32x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int pos = wstart + i0 + q;
+                            o[q] = (pos >= 0 && pos < Lin) ? relu_nan(d[u][q] + bv + 0.f) : 0.f;   // zero in the temporal padding
+                        }
+                        *reinterpret_cast<f32x4 *>(Bl + l15 * ROW + i0) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int cn = min(c0 + KCH, p.Cpad - KCH);
+        const float *wnext = wbase + (size_t)cn * p.Mpad;
+        {
+            const int cw = min(cn + (l15 & 7), p.C - 1);
+#pragma unroll
+            for (int s = 0; s < NA / 4; ++s) wgn[s] = f.gw[woff[s] + cw];
+            bvn = f.gbias[cw];
+        }
+        ws.issue_one(0, wnext);
+        ws.issue_one(1, wnext);
+        __builtin_amdgcn_s_setprio(1);
+        taps(0, 3);
+        __builtin_amdgcn_s_setprio(0);
+        ws.issue_one(2, wnext);
+        ws.issue_one(3, wnext);
+        __builtin_amdgcn_s_setprio(1);
+        taps(3, 6);
+        __builtin_amdgcn_s_setprio(0);
+        ws.issue_one(4, wnext);
+        __builtin_amdgcn_s_setprio(1);
+        taps(6, 9);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int s = 0; s < NA / 4; ++s) wg[s] = wgn[s];
+        bv = bvn;
+    }
+    const unsigned oslot[1] = {0u}, xslot[1] = {0u};
+    const int nval = min(NT, Qout - q0);
+    epilogue16<NB, 1, NT, true>(acc, p.bias, p.Cout, m0 + wave * 16 + l15, kq, false, p.relu != 0, p.out, p.out + (int64_t)seg * p.Cout * Qout,
+                                xslot, oslot, (int64_t)Qout, Qout, q0, nval, nval);
+}
+
 template <int V, int S, int KCH_ = (S == 1 ? 8 : 4)>
 int launch_stage16(TcnParams p, int n_seg, hipStream_t s) {
     typedef C16<V, S, KCH_> G;
@@ -307,4 +536,45 @@ int csk_launch_tcn_stage16(TcnParams p, int n_seg, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (p.V == 25) return p.stride == 1 ? launch_stage16<25, 1>(p, n_seg, s) : launch_stage16<25, 2>(p, n_seg, s);
     return p.stride == 1 ? launch_stage16<18, 1>(p, n_seg, s) : launch_stage16<18, 2>(p, n_seg, s);
+}
+
+template <int V, int CIN>
+static int launch_fused1(Fused1Params f, int n_seg, hipStream_t s) {
+    typedef C16<V, 1, 8> G;
+    TcnParams &p = f.t;
+    const int Q = p.Tout * V;
+    p.qtiles = (unsigned)((Q + G::NT - 1) / G::NT); p.mtiles = (unsigned)(p.Mpad / 64);
+    const int64_t grid = (int64_t)p.qtiles * p.mtiles * n_seg;
+    if (grid >= (1ll << 31)) CSK_FAIL("block1_fused: grid too large");
+    void (*kern)(Fused1Params) = block1_fused16_kernel<V, CIN>;
+    const size_t lds = (size_t)(G::WSZ + 8 * G::ROW + 4 * CIN * G::SPAN) * sizeof(float);
+    if (const int e = csk_ensure_lds((const void *)kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, f);
+    return (int)hipGetLastError();
+}
+
+// C ABI: see include/cskel.h (csk_block_few_channels_f32)
+extern "C" int csk_block_few_channels_f32(const float *x, const float *gcn_w, const float *gcn_bias, const int32_t *ell_src,
+                                          const float *ell_val, const int32_t *ell_cnt, int ell_w, const float *tcn_w,
+                                          const float *tcn_bias, float *out, int n_seg, int c_in, int c_mid, int c_out, int t_in,
+                                          int V, int pad, void *stream) {
+    if (!x || !gcn_w || !gcn_bias || !ell_src || !ell_val || !ell_cnt || !tcn_w || !tcn_bias || !out) CSK_FAIL("block_few_channels: null pointer");
+    if (n_seg <= 0 || t_in <= 0 || c_out <= 0) CSK_FAIL("block_few_channels: bad dims");
+    if (c_in < 1 || c_in > 4) CSK_FAIL("block_few_channels: built for 1..4 input channels (layer 1 of the stacks)");
+    if (V != 25 && V != 18) CSK_FAIL("block_few_channels: built for V = 25 / 18");
+    if (pad != 4 || c_mid < 8 || c_mid % 8) CSK_FAIL("block_few_channels: 9-tap temporal conv with padding 4, graph-conv channels a multiple of 8");
+    if (ell_cnt[0] > 1 || ell_cnt[1] > 1 || ell_cnt[2] > 4 || ell_w < 1) CSK_FAIL("block_few_channels: skeleton-sparse adjacency (<= 1 / 1 / 4 entries per column)");
+    if ((int64_t)c_mid * t_in * V * 4 >= (1ll << 31) || (int64_t)c_out * t_in * V * 4 >= (1ll << 31)) CSK_FAIL("block_few_channels: segment too large");
+    Fused1Params f{};
+    TcnParams &p = f.t;
+    p.w = tcn_w; p.bias = tcn_bias; p.out = out;
+    p.C = c_mid; p.Cpad = round_up(c_mid, CSK_CPAD); p.Cout = c_out; p.Mpad = round_up(c_out, CSK_MT);
+    p.Tin = t_in; p.Tout = t_in; p.V = V; p.K = 9; p.stride = 1; p.pad = pad; p.relu = 1; p.res_mode = CSK_RES_NONE; p.ksplit = 1;
+    f.x = x; f.gw = gcn_w; f.gbias = gcn_bias; f.ell_src = ell_src; f.ell_val = ell_val;
+    for (int k = 0; k < 3; ++k) f.ell_cnt[k] = ell_cnt[k];
+    f.ell_w = ell_w; f.Cin = c_in; f.CinPad = round_up(c_in, CSK_CPAD); f.GMpad = round_up(c_mid, CSK_MT);
+    hipStream_t s = (hipStream_t)stream;
+#define CSK_F1(V_) (c_in == 1 ? launch_fused1<V_, 1>(f, n_seg, s) : c_in == 2 ? launch_fused1<V_, 2>(f, n_seg, s) : c_in == 3 ? launch_fused1<V_, 3>(f, n_seg, s) : launch_fused1<V_, 4>(f, n_seg, s))
+    return V == 25 ? CSK_F1(25) : CSK_F1(18);
+#undef CSK_F1
 }

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcskel_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 # name -> argtypes; mirrors include/cskel.h line by line
@@ -20,6 +20,7 @@ SIGNATURES = {
     "csk_gcn_stage_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _p],
     "csk_gcn_stage_splitk_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _p, _p],
     "csk_tcn_stage_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "csk_block_few_channels_f32": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "csk_tcn_stage_splitk_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     "csk_conv1x1_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _p],
     "csk_tcn_stage_bf16x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSK_ABI_VERSION 14
+#define CSK_ABI_VERSION 15
 #define CSK_KC 8    /* channel-chunk of the K loop of the TCN kernels                                */
 #define CSK_CPAD 16 /* packed weights zero-pad C_in to a multiple of this                             */
 #define CSK_MT 64  /* packed weights pad C_out to a multiple of this                               */
@@ -114,6 +114,24 @@ int csk_tcn_stage_f32(const float *y, const float *w, const float *x_res, const 
                       const float *bias, float *out,
                       int n_seg, int c, int c_out, int t_in, int V, int k, int stride, int pad,
                       int res_mode, int c_res, int t_res, int res_off, int relu, void *stream);
+
+/*
+ * A whole SpatioTemporalBlock with a FEW input channels and no block residual -- layer 1 of the reference's stacks
+ * (models/st_gcn/st_gcn.py:30: StGcnBlock(3, 64, A, residual=False); block body models/base.py:376-387) -- in ONE launch:
+ *   out = ReLU( tcn( gcn(x) ) ),  gcn(x) = ReLU( sum_k W'_k . (x . A_k) + b' + conv1x1+BN(x) )   (models/base.py:230-270)
+ * csk_gcn_stage_f32 (conv gcn_residual) followed by csk_tcn_stage_f32 (k = 9, stride 1, pad 4, no residual), with the graph
+ * conv formed on the fly inside the temporal conv's tile: y never travels through memory (2 GB per batch-256 forward).  The
+ * results are BIT FOR BIT those of the two calls (the same fmaf chain in the graph conv's K order; zero in the frames of the
+ * temporal padding).
+ *  x        (n_seg, c_in, t_in, V) contiguous, 1 <= c_in <= 4;  out (n_seg, c_out, t_in, V)
+ *  gcn_w / gcn_bias / ell_*  the packed operands of csk_gcn_stage_f32 with the conv gcn_residual as 4th subset, c_mid outputs
+ *  tcn_w / tcn_bias          the packed operands of csk_tcn_stage_f32 (c_mid -> c_out, 9 taps)
+ *  V in {25, 18}; c_mid a multiple of 8; a skeleton-sparse adjacency (ell_cnt <= 1 / 1 / 4).  Other shapes: the two calls.
+ */
+int csk_block_few_channels_f32(const float *x, const float *gcn_w, const float *gcn_bias, const int32_t *ell_src,
+                               const float *ell_val, const int32_t *ell_cnt, int ell_w, const float *tcn_w,
+                               const float *tcn_bias, float *out, int n_seg, int c_in, int c_mid, int c_out, int t_in,
+                               int V, int pad, void *stream);
 
 /*
  * csk_tcn_stage_f32 for launches of a FEW tiles (small-batch clip inference; the reference's own CPU protocol is batch 1,

@@ -326,3 +326,27 @@ def test_clip_latency_mode_full_model_golden_and_batch_invariance():
     assert torch.equal(net(x4).cpu(), big) and torch.equal(big[:2], base)
     with pytest.raises(ValueError):
         pkg.set_clip_latency_mode(torch.nn.Linear(2, 2))
+
+
+@pytest.mark.parametrize("v,t,cin,co", [(25, 52, 3, 64), (25, 16, 3, 64), (25, 300, 3, 64), (18, 37, 3, 64), (25, 20, 2, 64), (18, 33, 4, 64),
+                                        (25, 7, 3, 64), (25, 40, 3, 128), (25, 24, 1, 8)])
+def test_first_block_as_one_launch_is_bitwise_the_two_launches(v, t, cin, co):
+    """csk_block_few_channels_f32 (layer 1 of the stacks, st_gcn.py:30: graph conv formed on the fly inside the temporal conv's
+    tile) against csk_gcn_stage_f32 + csk_tcn_stage_f32: bit for bit -- frame counts that are not whole 16-frame tiles, both
+    skeletons, 1-4 input channels, more than one m-tile; the input between NaN guards in the fused run."""
+    import bench
+    A_ = (pkg.ntu_graph() if v == 25 else pkg.kinetics_graph()).A
+    blk = pkg.SpatioTemporalBlock(cin, co, A_, residual=False).eval()
+    bench.randomise_(blk, cin + t)
+    blk = blk.to(DEV)
+    x = torch.rand((3, cin, t, v), generator=torch.Generator().manual_seed(t)).to(DEV)
+    buf = torch.full((x.numel() + 8192,), float("nan"), device=DEV)
+    xg = buf[4096: 4096 + x.numel()].view(x.shape)
+    xg.copy_(x)
+    blk.fuse_few_channels = True                              # opt-in (measured neutral in time: blocks.py)
+    assert blk._few_channels_fusable(xg)
+    one = blk(xg).cpu()
+    blk.fuse_few_channels = False
+    two = blk(x).cpu()
+    assert bool(torch.isfinite(one).all())
+    assert torch.equal(one, two)

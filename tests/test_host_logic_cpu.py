@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cskel.h but not exported"
     assert declared - {"csk_last_error"} == set(pkg.native.SIGNATURES), "ctypes table out of sync with cskel.h"
-    assert pkg.native.lib().csk_abi_version() == pkg.native.ABI_VERSION == 14
+    assert pkg.native.lib().csk_abi_version() == pkg.native.ABI_VERSION == 15
 
 
 def test_argument_errors_do_not_need_a_gpu():
