@@ -434,7 +434,16 @@ __global__ __launch_bounds__(NTHREADS) void agcn_softmax_parts_kernel(const floa
     const float *src = part + (int64_t)pair * nparts * V * V;
     for (int e = tid; e < V * V; e += NTHREADS) {
         float s = 0.f;
-        for (int t = 0; t < nparts; ++t) s += src[(int64_t)t * V * V + e];
+        // eight tiles' partial sums in flight per thread (a rolled loop waits for every load: ~43 dependent round trips at T = 300);
+        // the additions stay in tile order
+        for (int t0 = 0; t0 < nparts; t0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)min(t0 + u, nparts - 1) * V * V + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t0 + u < nparts) s += v[u];
+        }
         lg[(e / V) * 33 + e % V] = s / (float)K;
     }
     __syncthreads();
