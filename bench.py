@@ -729,7 +729,7 @@ def main():
                        "global_batch": B * world, "frames_per_clip": NTU["T"], "parallelism": f"batch-shard x{world}",
                        "skeleton_frames_per_s": round(clips / dt * NTU["T"], 1)},
             "roofline": {"bound": "mfma", "kernel": "tcn_stage_kernel + tcn_stage16_kernel (the csk_tcn_stage_f32 launches)", "achieved": round(achieved, 2),
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 6),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches_timed": n_launch,
                          "flops_per_launch": flops_launch,
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
@@ -783,7 +783,7 @@ def main():
                 "steps": steps5, "ms_per_step": round(dt5 / steps5 * 1e3, 3),
                 # the dominant kernel of this leg, timed live on rank 0 exactly as the headline's (HIP events around every launch)
                 "roofline": {"bound": "mfma", "kernel": "tcn_stage_kernel + tcn_stage16_kernel (the csk_tcn_stage_f32 launches)", "achieved": round(ach5, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                             "unit": "TFLOP/s", "frac": round(ach5 / PEAK_F32_MFMA_TFLOPS, 4),
+                             "unit": "TFLOP/s", "frac": round(ach5 / PEAK_F32_MFMA_TFLOPS, 6),
                              "avg_launch_ms": round(tcn5_ms / max(1, n5), 4), "launches_timed": n5, "flops_per_launch": fl5,
                              "traffic": traffic5["hbm_bytes_per_launch"] if traffic5 else None,
                              "traffic_source": (f"{traffic5.get('source')} (committed rocprofv3 --pmc passes at this batch, not collected by this run)")
@@ -824,7 +824,7 @@ def main():
                      "predictions_per_s": round(fps / 4, 1), "state_slab_GB_per_gpu": round(sbytes[0] / 1e9, 3),
                      "split_k_scratch_GB_per_gpu": round(sbytes[1] / 1e9, 3),
                      "roofline": {"bound": "mfma", "kernel": "tcn_step16_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_timed": sn,
+                                  "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 6), "launches_timed": sn,
                                   "avg_launch_ms": round(stcn_ms / max(1, sn), 4),
                                   "flops_per_launch": tfl / len(step_layers),
                                   "timing": "single stream shard, launches driven from Python with HIP events around every "

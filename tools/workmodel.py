@@ -109,9 +109,9 @@ def roofline_config(flops_alg, bytes_alg, t_measured_s, flops_exec=None, n_gpus=
                 peak_tflops=round(PEAK_F32_MFMA_TFLOPS * n_gpus, 1), peak_hbm_tbs=round(PEAK_HBM_TBS * n_gpus, 1),
                 t_mfma_ms=round(t_mfma * 1e3, 4),
                 t_hbm_ms=round(t_hbm * 1e3, 4), t_roof_ms=round(t_roof * 1e3, 4), t_measured_ms=round(t_measured_s * 1e3, 4),
-                bound="mfma" if t_mfma >= t_hbm else "hbm", frac=round(t_roof / t_measured_s, 4),
-                frac_executed=round(t_roof / t_measured_s, 4),
-                frac_alg=round(max(t_mfma_alg, t_hbm) / t_measured_s, 4),
+                bound="mfma" if t_mfma >= t_hbm else "hbm", frac=round(t_roof / t_measured_s, 6),
+                frac_executed=round(t_roof / t_measured_s, 6),
+                frac_alg=round(max(t_mfma_alg, t_hbm) / t_measured_s, 6),   # (6 digits: toy-size runs sharing a GPU must not round to 0)
                 achieved_tflops=round(fe / t_measured_s / 1e12, 2),
                 achieved_tflops_per_gpu=round(fe / t_measured_s / 1e12 / n_gpus, 2),
                 achieved_hbm_alg_tbs=round(bytes_alg / t_measured_s / 1e12, 3))
